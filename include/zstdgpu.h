@@ -1,0 +1,182 @@
+/*
+ * zstdgpu.h -- C ABI of the MI355X batched zstd decompressor.
+ *
+ * Drop-in boundary for the one-shot decode path of the Free Pascal zstd port
+ * (terrylao/zstd): every entry point below names the Pascal routine it replaces
+ * (file:line relative to the reference tree).  Plain C types only; all functions are
+ * `cdecl`, never throw, and never call back into the host program.
+ *
+ * Error convention: upstream zstd's -- a size_t result that is either a byte count or
+ * (size_t)-code with code from ZSTD_ErrorCode (common/error_private.pas:6-36).  The
+ * port's own ERROR()/ERR_isError (common/error_private.pas:44-51) are inverted and are
+ * not reproduced; use zstdgpu_isError().
+ */
+#ifndef ZSTDGPU_H
+#define ZSTDGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZSTDGPU_VERSION_NUMBER 10408u                /* decodes the zstd 1.4.8 format (common/zstd.pas:13-15) */
+#define ZSTDGPU_CONTENTSIZE_UNKNOWN (0ULL - 1)       /* upstream sentinels; the port's 32-bit ones (common/zstd.pas:19-20) are a defect */
+#define ZSTDGPU_CONTENTSIZE_ERROR   (0ULL - 2)
+#define ZSTDGPU_BLOCKSIZE_MAX (1u << 17)             /* common/zstd.pas:12 */
+
+typedef struct zstdgpu_ctx zstdgpu_ctx;       /* replaces ZSTD_DCtx (decompress/zstd_ddict.pas:109-170): one per GPU, single-owner */
+typedef struct zstdgpu_ddict zstdgpu_ddict;   /* replaces ZSTD_DDict (decompress/zstd_ddict.pas:84-92): digested tables + content in HBM */
+typedef struct zstdgpu_batch zstdgpu_batch;   /* a prepared batch: device descriptors + scratch, reusable across launches */
+
+/* ---- error helpers: ZSTD_isError / ZSTD_getErrorCode / ZSTD_getErrorName (common/error_private.pas:38-41, :66-106) ---- */
+unsigned    zstdgpu_isError(size_t code);
+unsigned    zstdgpu_getErrorCode(size_t code);
+const char* zstdgpu_getErrorName(size_t code);
+unsigned    zstdgpu_versionNumber(void);
+
+/* ---- context: ZSTD_createDCtx / ZSTD_freeDCtx (decompress/zstd_decompressf.pas:169, :183) ----
+ * `device` is a HIP device ordinal.  Returns NULL when no usable GPU/extension is present
+ * (there is no CPU fallback). */
+zstdgpu_ctx* zstdgpu_create(int device);
+void         zstdgpu_destroy(zstdgpu_ctx* ctx);
+
+/* ---- host-side header queries (stay on the host, as in the reference) ----
+ * ZSTD_getFrameContentSize (decompress/zstd_decompressf.pas:414), ZSTD_findFrameCompressedSize (:646),
+ * ZSTD_getDictID_fromDict (:1455), ZSTD_getDictID_fromFrame (:1473). */
+unsigned long long zstdgpu_getFrameContentSize(const void* src, size_t srcSize);
+size_t             zstdgpu_findFrameCompressedSize(const void* src, size_t srcSize);
+unsigned           zstdgpu_getDictID_fromDict(const void* dict, size_t dictSize);
+unsigned           zstdgpu_getDictID_fromFrame(const void* src, size_t srcSize);
+
+/* ---- dictionaries: ZSTD_createDDict / ZSTD_freeDDict (decompress/zstd_ddict.pas:294-326) ----
+ * Copies the dictionary to the GPU and digests its entropy tables there once
+ * (ZSTD_loadDEntropy, decompress/zstd_decompressf.pas:1261-1356).  NULL on allocation failure;
+ * a dictionary with a corrupted entropy section yields a ddict whose use returns dictionary_corrupted. */
+zstdgpu_ddict* zstdgpu_createDDict(zstdgpu_ctx* ctx, const void* dict, size_t dictSize);
+void           zstdgpu_freeDDict(zstdgpu_ddict* ddict);
+
+/* ---- one-shot drop-ins, host buffers in and out ----
+ * ZSTD_decompress (decompress/zstd_decompressf.pas:977), ZSTD_decompressDCtx (:971),
+ * ZSTD_decompress_usingDict (:944), ZSTD_decompress_usingDDict (:1496).
+ * `src` may hold several concatenated and skippable frames (ZSTD_decompressMultiFrame, :836-942). */
+size_t zstdgpu_decompress(void* dst, size_t dstCapacity, const void* src, size_t srcSize);
+size_t zstdgpu_decompressDCtx(zstdgpu_ctx* ctx, void* dst, size_t dstCapacity, const void* src, size_t srcSize);
+size_t zstdgpu_decompress_usingDict(zstdgpu_ctx* ctx, void* dst, size_t dstCapacity, const void* src, size_t srcSize,
+                                    const void* dict, size_t dictSize);
+size_t zstdgpu_decompress_usingDDict(zstdgpu_ctx* ctx, void* dst, size_t dstCapacity, const void* src, size_t srcSize,
+                                     const zstdgpu_ddict* ddict);
+
+/* ---- descriptor level: what the host-side block loop emits instead of decoding ----
+ * The frame loop of ZSTD_decompressFrame (decompress/zstd_decompressf.pas:734-834) keeps parsing the
+ * frame header (ZSTD_getFrameHeader_advanced, :281-395) and each 3-byte block header
+ * (ZSTD_getcBlockSize, decompress/zstd_decompress_block.pas:190-207); instead of calling
+ * ZSTD_decompressBlock_internal / ZSTD_copyRawBlock / ZSTD_setRleBlock it appends one
+ * zstdgpu_block_desc per block.  Offsets are relative to one source buffer that exists both in
+ * host memory (headers are read there) and in device memory (payloads are read there). */
+typedef struct {
+    uint64_t srcOff;        /* first byte of the frame (its magic number) */
+    uint64_t srcSize;       /* bytes of this frame, checksum included */
+    uint64_t dstOff;        /* where the regenerated bytes go, relative to the destination buffer */
+    uint64_t dstCapacity;   /* room at dstOff */
+    uint64_t contentSize;   /* frame content size or ZSTDGPU_CONTENTSIZE_UNKNOWN */
+    uint64_t windowSize;
+    uint32_t firstBlock;    /* index of the frame's first zstdgpu_block_desc */
+    uint32_t nBlocks;
+    uint32_t dictID;
+    uint32_t checksumFlag;  /* 1: a 4-byte XXH64 trailer follows the last block */
+    uint32_t checksum;      /* the trailer, read little-endian (valid when checksumFlag) */
+    uint32_t hostError;     /* ZSTD_ErrorCode found while walking headers; the frame is then not decoded */
+} zstdgpu_frame_desc;
+
+typedef struct {
+    uint64_t srcOff;        /* first byte after the 3-byte block header */
+    uint32_t cSize;         /* payload bytes present in the source (1 for an RLE block) */
+    uint32_t origSize;      /* RLE: regenerated size; raw: == cSize; compressed: unused */
+    uint32_t frameIdx;
+    uint8_t  blockType;     /* 0 raw, 1 RLE, 2 compressed (blockType_e, common/zstd_internal.pas:112-118) */
+    uint8_t  lastBlock;
+    uint16_t hostError;     /* ZSTD_ErrorCode hit at this point of the walk (e.g. reserved block type): decoding of the frame stops here */
+} zstdgpu_block_desc;
+
+typedef struct {
+    uint32_t errorCode;     /* 0 or a ZSTD_ErrorCode */
+    uint32_t xxh64Low32;    /* low 32 bits of XXH64(content, seed 0) when the frame carries a checksum */
+    uint64_t regenSize;     /* bytes written at dstOff */
+} zstdgpu_frame_status;
+
+/* One source frame of a batch: where it is and where its output goes. */
+typedef struct {
+    uint64_t srcOff, srcSize, dstOff, dstCapacity;
+} zstdgpu_frame_in;
+
+/* C mirror of the host descriptor builder: walks the frame and block headers of each listed frame
+ * (one zstd frame each) in host memory and fills the descriptor arrays.  `blocks` may be NULL to
+ * count only.  Returns the number of block descriptors needed/written, or an error if
+ * blockCapacity is too small (dstSize_tooSmall). */
+size_t zstdgpu_buildDescriptors(const void* hostSrc, size_t srcBytes,
+                                const zstdgpu_frame_in* in, uint32_t nFrames,
+                                zstdgpu_frame_desc* frames,
+                                zstdgpu_block_desc* blocks, size_t blockCapacity);
+
+/* Prepare a batch from descriptors: parses literal/sequence section headers on the host
+ * (the header switch of ZSTD_decodeLiteralsBlock, decompress/zstd_decompress_block.pas:243-274, :333-400,
+ * and the count/modes bytes of ZSTD_decodeSeqHeaders, :708-742), links repeat-mode tables to the
+ * block that defines them, sizes and allocates device scratch, uploads everything.
+ * `ddict` may be NULL.  Returns NULL on allocation failure. */
+zstdgpu_batch* zstdgpu_batch_create(zstdgpu_ctx* ctx, const void* hostSrc, size_t srcBytes,
+                                    const zstdgpu_frame_desc* frames, uint32_t nFrames,
+                                    const zstdgpu_block_desc* blocks, uint32_t nBlocks,
+                                    const zstdgpu_ddict* ddict);
+/* Convenience: zstdgpu_buildDescriptors + zstdgpu_batch_create. */
+zstdgpu_batch* zstdgpu_batch_create_from_frames(zstdgpu_ctx* ctx, const void* hostSrc, size_t srcBytes,
+                                                const zstdgpu_frame_in* in, uint32_t nFrames,
+                                                const zstdgpu_ddict* ddict);
+void zstdgpu_batch_destroy(zstdgpu_batch* batch);
+
+/* Launch the whole stage chain (literals, sequence decode, layout, sequence execution, XXH64,
+ * verdict) for the batch on `stream` (a hipStream_t, NULL = default stream).  `devSrc`/`devDst`
+ * are device pointers to the source and destination buffers the descriptors index.
+ * Asynchronous; allocates nothing.  Returns 0 or an error code (GENERIC on a launch failure). */
+size_t zstdgpu_batch_decode(zstdgpu_batch* batch, const void* devSrc, void* devDst, void* stream);
+
+/* Wait for the last launch and copy the per-frame verdicts out (`status` has nFrames entries). */
+size_t zstdgpu_batch_status(zstdgpu_batch* batch, zstdgpu_frame_status* status);
+
+/* Batch facts for measurement: totals over frames without a host error. */
+uint32_t zstdgpu_batch_nFrames(const zstdgpu_batch* batch);
+uint32_t zstdgpu_batch_nBlocks(const zstdgpu_batch* batch);
+uint64_t zstdgpu_batch_srcBytes(const zstdgpu_batch* batch);      /* sum of frame srcSize (C) */
+uint64_t zstdgpu_batch_scratchBytes(const zstdgpu_batch* batch);  /* device scratch held */
+
+/* Per-stage timing of the next launches: when enabled, zstdgpu_batch_decode brackets each kernel
+ * with HIP events on the launch stream; zstdgpu_batch_stage_ms (after zstdgpu_batch_status or a
+ * stream sync) returns the milliseconds of the last launch, ZSTDGPU_NUM_STAGES floats. */
+#define ZSTDGPU_NUM_STAGES 6
+#define ZSTDGPU_STAGE_LITERALS 0   /* Huffman table build + literal streams */
+#define ZSTDGPU_STAGE_SEQUENCES 1  /* FSE table build + sequence decode */
+#define ZSTDGPU_STAGE_LAYOUT 2     /* per-frame block offsets and repeat-offset hand-over */
+#define ZSTDGPU_STAGE_EXECUTE 3    /* sequence execution + raw/RLE blocks */
+#define ZSTDGPU_STAGE_CHECKSUM 4   /* XXH64 + frame verdict */
+#define ZSTDGPU_STAGE_TOTAL 5      /* first launch to last completion */
+void   zstdgpu_batch_set_profiling(zstdgpu_batch* batch, int enabled);
+size_t zstdgpu_batch_stage_ms(zstdgpu_batch* batch, float* ms);
+const char* zstdgpu_stage_kernel_name(int stage);
+
+/* ---- stage-level hooks, for checking single kernels against the units they replace ---- */
+/* XXH64 of n device buffers (xxhash.pas:409-488): digests[i] = XXH64(devBase+off[i], len[i], seed 0). */
+size_t zstdgpu_xxh64Batch(zstdgpu_ctx* ctx, const void* devBase, const uint64_t* off, const uint64_t* len,
+                          uint32_t n, uint64_t* digests);
+/* Intermediates of the last launch, copied to host arrays (any may be NULL):
+ * literals of compressed blocks as decoded by stage 0 (ZSTD_decodeLiteralsBlock), sequences as
+ * decoded by stage 1 with repeat offsets resolved (ZSTD_decodeSequence), per block. */
+size_t zstdgpu_batch_blockInfo(zstdgpu_batch* batch, uint32_t blockIdx,
+                               uint32_t* litSize, uint32_t* nbSeq, uint64_t* regenSize, uint32_t* errorCode);
+size_t zstdgpu_batch_copyLiterals(zstdgpu_batch* batch, const void* devSrc, uint32_t blockIdx, void* out, size_t outCapacity);
+size_t zstdgpu_batch_copySequences(zstdgpu_batch* batch, uint32_t blockIdx, uint32_t* triples, size_t tripleCapacity);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZSTDGPU_H */

@@ -1,0 +1,71 @@
+import hashlib
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_manifest():
+    with open(os.path.join(GOLD, "manifest.json")) as f:
+        return json.load(f)
+
+
+MANIFEST = load_manifest()
+FRAMES = MANIFEST["frames"]
+FRAME_IDS = [e["name"] for e in FRAMES]
+
+
+def read_frame(e) -> bytes:
+    with open(os.path.join(GOLD, e["file"]), "rb") as f:
+        return f.read()
+
+
+_dict_cache = {}
+
+
+def read_dict(name):
+    if name is None:
+        return None
+    if name not in _dict_cache:
+        meta = MANIFEST["dicts"][name]
+        with open(os.path.join(GOLD, meta["file"]), "rb") as f:
+            d = f.read()
+        assert hashlib.sha256(d).hexdigest() == meta["sha256"]
+        _dict_cache[name] = d
+    return _dict_cache[name]
+
+
+def regenerate(source) -> bytes:
+    """Plain bytes of a fixture from its recorded generator and seed."""
+    from zstd_amd import corpus
+    import random
+    g = source["gen"]
+    if g == "text":
+        return corpus.text_like(source["seed"], source["n"])
+    if g == "bin":
+        return corpus.binary_records(source["seed"], source["n"])
+    if g == "periodic":
+        rnd = random.Random(source["seed"])
+        unit = bytes(rnd.randrange(256) for _ in range(source["period"]))
+        n = source["n"]
+        return (unit * (n // source["period"] + 1))[:n]
+    raise KeyError(g)
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built():
+    """Build the CPU-side helpers (oracle, corpus generator) if missing; the GPU library is prebuilt in-tree."""
+    from zstd_amd import build
+    build.build_corpus()
+    build.build_oracle()
+    yield

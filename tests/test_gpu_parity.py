@@ -1,0 +1,219 @@
+"""Parity of the HIP decoder with the CPU oracle, through the C ABI.  Bit-exact: byte, integer and
+index work only.  Expected results come from the oracle run on the same input and from the golden
+manifest (libzstd 1.4.8's verdicts)."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import FRAMES, FRAME_IDS, read_frame, read_dict, regenerate
+from oracle import oracle
+from zstd_amd import api
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dctx():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the GPU"
+    d = api.DCtx(0)
+    yield d
+    d.close()
+
+
+def dev(arr: np.ndarray):
+    import torch
+    return torch.from_numpy(arr).cuda()
+
+
+# ------------------------------------------------------------------ one-shot drop-ins
+@pytest.mark.parametrize("e", FRAMES, ids=FRAME_IDS)
+def test_oneshot_matches_oracle_and_manifest(dctx, e):
+    fr = read_frame(e)
+    d = read_dict(e.get("dict"))
+    want, werr = oracle.decompress(fr, e["capacity"], d)
+    try:
+        if d is not None:
+            got = api.ZSTD_decompress_usingDict(dctx, fr, e["capacity"], d)
+        else:
+            got = api.ZSTD_decompressDCtx(dctx, fr, e["capacity"])
+        gerr = 0
+    except api.ZstdError as ex:
+        got, gerr = None, ex.code
+    assert gerr == werr == e.get("error", 0)
+    if not gerr:
+        assert got == want
+        assert hashlib.sha256(got).hexdigest() == e["sha256"]
+
+
+def test_zstd_decompress_creates_its_own_context():
+    e = next(x for x in FRAMES if x["name"] == "text4096_l3_c1")
+    assert api.ZSTD_decompress(read_frame(e), e["capacity"]) == regenerate(e["source"])
+
+
+def test_config1_round_trip(dctx):
+    """BASELINE config 1: level-1 frame of a 1 MB text buffer decodes to the original bytes."""
+    e = next(x for x in FRAMES if x["name"] == "text1m_l1")
+    assert api.ZSTD_decompressDCtx(dctx, read_frame(e), e["capacity"]) == regenerate(e["source"])
+
+
+def test_ddict_reuse(dctx):
+    d = read_dict("dict16k")
+    dd = api.DDict(dctx, d)
+    for e in FRAMES:
+        if e.get("dict") == "dict16k" and "error" not in e:
+            want, _ = oracle.decompress(read_frame(e), e["capacity"], d)
+            assert api.ZSTD_decompress_usingDDict(dctx, read_frame(e), e["capacity"], dd) == want
+    dd.close()
+
+
+# ------------------------------------------------------------------ batched path on device buffers
+def run_batch(dctx, entries, ddict=None, via_descriptors=False):
+    frames = [read_frame(e) for e in entries]
+    caps = [e["capacity"] for e in entries]
+    src, fin, dst_bytes = api.pack_frames(frames, caps)
+    d_src = dev(src)
+    import torch
+    d_dst = torch.zeros(dst_bytes, dtype=torch.uint8, device="cuda")
+    b = api.Batch(dctx, src, fin, ddict, via_descriptors=via_descriptors)
+    b.decode(d_src.data_ptr(), d_dst.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    st = b.status()
+    out = d_dst.cpu().numpy()
+    return b, d_src, fin, st, out
+
+
+@pytest.mark.parametrize("via_descriptors", [False, True])
+def test_batch_mixed_valid_and_corrupt(dctx, via_descriptors):
+    """One launch over every dictionary-less single-frame fixture, valid and corrupt together: each
+    frame gets its own verdict, a corrupt neighbour does not disturb a valid frame."""
+    entries = [e for e in FRAMES if "dict" not in e and e["capacity"] <= (1 << 20)
+               and not e["name"].startswith(("concat", "skippable", "rec_nodict"))]
+    b, d_src, fin, st, out = run_batch(dctx, entries, via_descriptors=via_descriptors)
+    for i, e in enumerate(entries):
+        want, werr = oracle.decompress(read_frame(e), e["capacity"])
+        assert int(st[i]["errorCode"]) == werr, e["name"]
+        if not werr:
+            o = int(fin[i]["dstOff"])
+            assert int(st[i]["regenSize"]) == len(want), e["name"]
+            assert out[o:o + len(want)].tobytes() == want, e["name"]
+    b.close()
+
+
+def test_batch_with_dictionary(dctx):
+    d = read_dict("dict16k")
+    dd = api.DDict(dctx, d)
+    entries = [e for e in FRAMES if e.get("dict") == "dict16k"]
+    b, d_src, fin, st, out = run_batch(dctx, entries, ddict=dd)
+    for i, e in enumerate(entries):
+        want, werr = oracle.decompress(read_frame(e), e["capacity"], d)
+        assert int(st[i]["errorCode"]) == werr
+        o = int(fin[i]["dstOff"])
+        assert out[o:o + len(want)].tobytes() == want
+    b.close()
+    dd.close()
+
+
+def test_batch_checksum_value(dctx):
+    entries = [e for e in FRAMES if e["name"] in ("text128k_l19_c1", "bin512k_l3_c1", "empty_c1", "text33_l3_c1")]
+    b, d_src, fin, st, out = run_batch(dctx, entries)
+    for i, e in enumerate(entries):
+        want, _ = oracle.decompress(read_frame(e), e["capacity"])
+        assert int(st[i]["xxh64Low32"]) == oracle.xxh64(want) & 0xFFFFFFFF
+    b.close()
+
+
+# ------------------------------------------------------------------ stage level
+@pytest.mark.parametrize("name", ["text128k_l3_c0", "bin128k_l19_c1", "text1m_l1", "manyseq_longcount_l19", "alpha16_l19",
+                                  "text300k_l19_c1", "farmatch_l19", "rle300k", "text255_l3_c1", "text4096_l3_c1"])
+def test_stage_intermediates_match_oracle_trace(dctx, name):
+    """Literals (stage 0) and sequences with resolved repeat offsets (stage 1) of every compressed
+    block equal what ZSTD_decodeLiteralsBlock / ZSTD_decodeSequence produce in the oracle."""
+    e = next(x for x in FRAMES if x["name"] == name)
+    t = oracle.decompress_traced(read_frame(e), e["capacity"])
+    assert t["err"] == 0
+    b, d_src, fin, st, out = run_batch(dctx, [e])
+    assert int(st[0]["errorCode"]) == 0
+    fds, bds, nb = api.build_descriptors(*api.pack_frames([read_frame(e)], [e["capacity"]])[:2])
+    comp = [i for i in range(nb) if bds[i].blockType == 2]
+    assert len(comp) == len(t["blk_lit_size"])
+    lpos = spos = 0
+    for k, bi in enumerate(comp):
+        info = b.block_info(bi)
+        assert info["error"] == 0
+        assert info["litSize"] == int(t["blk_lit_size"][k])
+        assert info["nbSeq"] == int(t["blk_nb_seq"][k])
+        assert info["regen"] == int(t["blk_regen"][k])
+        lit = b.literals(d_src.data_ptr(), bi)
+        assert lit == t["lits"][lpos:lpos + info["litSize"]].tobytes()
+        seqs = b.sequences(bi)
+        assert np.array_equal(seqs, t["seqs"][spos:spos + info["nbSeq"]])
+        lpos += info["litSize"]
+        spos += info["nbSeq"]
+    b.close()
+
+
+def test_xxh64_stage(dctx):
+    rng = np.random.default_rng(5)
+    lens = list(range(0, 70)) + [127, 128, 129, 1000, 4095, 4096, 4097, 131072, 1 << 20]
+    blob = rng.integers(0, 256, size=sum(lens) + 8, dtype=np.uint8)
+    offs = np.cumsum([0] + lens[:-1])
+    d = dev(blob)
+    got = api.xxh64_batch(dctx, d.data_ptr(), offs, lens)
+    for o, n, g in zip(offs, lens, got):
+        assert int(g) == oracle.xxh64(blob[o:o + n].tobytes()), n
+
+
+# ------------------------------------------------------------------ larger shapes: size-independent properties
+def test_many_frames_round_trip(dctx):
+    """256 independent 128 KB frames (the benchmark shape at 1/16 scale): compress -> batched decode
+    is the identity, checked through XXH64 of every output against XXH64 of the generator's bytes."""
+    from zstd_amd import corpus
+    if not corpus.SystemZstd.available():
+        pytest.skip("no system libzstd to compress with")
+    import torch
+    z = corpus.SystemZstd()
+    n = 256
+    plain = [corpus.mixed(1000 + i, 131072) for i in range(n)]
+    frames = [z.compress(p, (1, 3, 19)[i % 3] if i % 16 == 0 else 3, checksum=bool(i & 1)) for i, p in enumerate(plain)]
+    src, fin, dst_bytes = api.pack_frames(frames, [131072] * n)
+    d_src = dev(src)
+    d_dst = torch.zeros(dst_bytes, dtype=torch.uint8, device="cuda")
+    b = api.Batch(dctx, src, fin)
+    for _ in range(2):    # a batch is reusable: second launch gives the same result
+        d_dst.zero_()
+        b.decode(d_src.data_ptr(), d_dst.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        st = b.status()
+        assert not st["errorCode"].any()
+        assert (st["regenSize"] == 131072).all()
+        got = api.xxh64_batch(dctx, d_dst.data_ptr(), fin["dstOff"], st["regenSize"])
+        want = [oracle.xxh64(p) for p in plain]
+        assert [int(x) for x in got] == want
+    out = d_dst.cpu().numpy()
+    for i in (0, 1, 100, 255):
+        o = int(fin[i]["dstOff"])
+        assert out[o:o + 131072].tobytes() == plain[i]
+    b.close()
+
+
+def test_truncated_capacity_and_isolated_errors(dctx):
+    """dstCapacity one byte short fails with dstSize_tooSmall and writes nothing past its slot."""
+    e = next(x for x in FRAMES if x["name"] == "text128k_l3_c0")
+    fr = read_frame(e)
+    import torch
+    frames, caps = [fr, fr, fr], [131072, 131071, 131072]
+    src, fin, dst_bytes = api.pack_frames(frames, caps)
+    d_src = dev(src)
+    d_dst = torch.full((dst_bytes,), 0xAA, dtype=torch.uint8, device="cuda")
+    b = api.Batch(dctx, src, fin)
+    b.decode(d_src.data_ptr(), d_dst.data_ptr(), 0)
+    st = b.status()
+    assert [int(x) for x in st["errorCode"]] == [0, 70, 0]
+    out = d_dst.cpu().numpy()
+    want = regenerate(e["source"])
+    assert out[0:131072].tobytes() == want
+    o2 = int(fin[2]["dstOff"])
+    assert out[o2:o2 + 131072].tobytes() == want
+    o1 = int(fin[1]["dstOff"])
+    assert (out[o1 + 131071:o2] == 0xAA).all()
+    b.close()

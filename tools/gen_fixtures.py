@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/: compressed frames + what libzstd 1.4.8 says about each.
+
+The reference tree ships no golden vectors (its test program has an empty main), so the pins
+are produced here with the system libzstd.so.1.4.8 -- the upstream release the reference is a
+port of -- used as compressor and as reference decoder.  For every fixture the manifest
+records libzstd's verdict: regenerated size + sha256, or its error code.  Run in the build
+container only (the GPU box never needs libzstd); the outputs are committed.
+
+    python tools/gen_fixtures.py
+"""
+import hashlib
+import json
+import os
+import random
+import struct
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from zstd_amd import corpus  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+KB = 1024
+
+
+def periodic(period: int, n: int, seed: int) -> bytes:
+    rnd = random.Random(seed)
+    unit = bytes(rnd.randrange(256) for _ in range(period))
+    return (unit * (n // period + 1))[:n]
+
+
+def small_alphabet(seed: int, n: int, k: int) -> bytes:
+    rnd = random.Random(seed)
+    return bytes(rnd.choice(b"ACGTNXYZ01234567"[:k]) for _ in range(n))
+
+
+def many_sequences(seed: int, n: int, n_words: int = 48, lens=(3, 4)) -> bytes:
+    """3-4 byte words from a small set, each followed by one random byte: one sequence per ~4.5 bytes."""
+    rnd = random.Random(seed)
+    words = [bytes(rnd.randrange(256) for _ in range(rnd.choice(lens))) for _ in range(n_words)]
+    out = bytearray()
+    while len(out) < n:
+        out += rnd.choice(words)
+        out.append(rnd.randrange(256))
+    return bytes(out[:n])
+
+
+def records(seed: int, n_records: int, size: int = 4096):
+    """Structured ~200-byte rows packed into `size`-byte records (the dictionary workload)."""
+    rnd = random.Random(seed)
+    cities = ["amsterdam", "bangalore", "chicago", "dresden", "edinburgh", "fukuoka", "geneva", "houston"]
+    out = []
+    for r in range(n_records):
+        rows = []
+        while sum(len(x) for x in rows) < size:
+            rows.append(('{"id": %d, "user": "user_%05d", "city": "%s", "score": %.1f, "active": %s, "tags": ["t%d", "t%d"], '
+                         '"ts": "2024-%02d-%02dT%02d:%02d:%02dZ"}\n' % (
+                             rnd.randrange(10 ** 6), rnd.randrange(10 ** 5), rnd.choice(cities), rnd.gauss(100, 15),
+                             rnd.choice(("true", "false")), rnd.randrange(40), rnd.randrange(40), rnd.randrange(1, 13),
+                             rnd.randrange(1, 29), rnd.randrange(24), rnd.randrange(60), rnd.randrange(60))).encode())
+        out.append(b"".join(rows)[:size])
+    return out
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    for f in os.listdir(OUT):
+        os.remove(os.path.join(OUT, f))
+    z = corpus.SystemZstd()
+    assert z.version == "1.4.8", z.version
+    manifest = {"generator": "tools/gen_fixtures.py", "libzstd": z.version, "frames": [], "dicts": {}}
+
+    def add(name, frame, capacity, dictionary=None, note="", source=None):
+        out, err = z.decompress(frame, capacity, dictionary=manifest_dict_bytes.get(dictionary))
+        with open(os.path.join(OUT, name + ".zst"), "wb") as f:
+            f.write(frame)
+        e = {"name": name, "file": name + ".zst", "capacity": capacity, "csize": len(frame), "note": note}
+        if dictionary:
+            e["dict"] = dictionary
+        if source:
+            e["source"] = source   # how tests can regenerate the plain bytes
+        if err:
+            e["error"] = err
+        else:
+            e["size"] = len(out)
+            e["sha256"] = hashlib.sha256(out).hexdigest()
+        manifest["frames"].append(e)
+        return out, err
+
+    manifest_dict_bytes = {}
+
+    # ---- plain corpora at the benchmark block shape -------------------------------------------
+    for kind, gen in (("text", corpus.text_like), ("bin", corpus.binary_records)):
+        for lvl in (1, 3, 19):
+            for ck in (0, 1):
+                data = gen(7, 128 * KB)
+                add(f"{kind}128k_l{lvl}_c{ck}", z.compress(data, lvl, bool(ck)), len(data),
+                    note="one full 128 KB block", source={"gen": kind, "seed": 7, "n": 128 * KB})
+    # C1: 1 MB text, level 1, 8 blocks, window 2^19; and multi-block level 3 / 19 (repeat tables, cross-block matches)
+    data = corpus.text_like(1, 1 << 20)
+    add("text1m_l1", z.compress(data, 1), len(data), note="config 1 round trip", source={"gen": "text", "seed": 1, "n": 1 << 20})
+    data = corpus.binary_records(3, 512 * KB)
+    add("bin512k_l3_c1", z.compress(data, 3, True), len(data), note="4 blocks, checksum", source={"gen": "bin", "seed": 3, "n": 512 * KB})
+    data = corpus.text_like(5, 300 * KB)
+    add("text300k_l19_c1", z.compress(data, 19, True), len(data), note="3 blocks btultra2", source={"gen": "text", "seed": 5, "n": 300 * KB})
+    add("text300k_l3_nocsize", z.compress(data, 3, False, content_size=False), len(data), note="frame content size absent",
+        source={"gen": "text", "seed": 5, "n": 300 * KB})
+    add("text300k_l3_cap_big", z.compress(data, 3), len(data) + 1000, note="capacity larger than content",
+        source={"gen": "text", "seed": 5, "n": 300 * KB})
+    add("text300k_l3_cap_small", z.compress(data, 3), len(data) - 1, note="capacity too small -> dstSize_tooSmall")
+
+    # ---- tiny and degenerate frames ---------------------------------------------------------------
+    add("empty_c0", z.compress(b"", 3), 0, note="empty frame")
+    add("empty_c1", z.compress(b"", 3, True), 0, note="empty frame with checksum")
+    for n in (1, 2, 5, 31, 32, 33, 100, 255, 256, 257, 1000, 4096):
+        data = corpus.text_like(100 + n, n)
+        add(f"text{n}_l3_c1", z.compress(data, 3, True), n, note="small frame", source={"gen": "text", "seed": 100 + n, "n": n})
+    for n in (300, 2000, 20000):
+        data = corpus.text_like(200 + n, n)
+        add(f"text{n}_l19", z.compress(data, 19), n, note="small frame btultra2", source={"gen": "text", "seed": 200 + n, "n": n})
+
+    # ---- block types ----------------------------------------------------------------------------------
+    add("rle300k", z.compress(b"a" * (300 * KB), 3, True), 300 * KB, note="RLE blocks after the first")
+    rnd = random.Random(11)
+    noise = bytes(rnd.getrandbits(8) for _ in range(200 * KB))
+    add("raw200k", z.compress(noise, 3, True), len(noise), note="raw (incompressible) blocks")
+    add("mixed_rle_raw_text", z.compress(b"q" * 200000 + noise[:150000] + corpus.text_like(9, 200000), 3, True), 550000,
+        note="RLE, raw and compressed blocks in one frame")
+    # literals modes: Huffman-only (no sequences), RLE literals, 1-stream, 4-stream; tiny alphabets
+    for k, n in ((2, 30000), (4, 50000), (16, 100000), (16, 200)):
+        add(f"alpha{k}_{n}", z.compress(small_alphabet(k * 1000 + n, n, k), 3), n, note="few/no sequences, Huffman literals")
+    add("alpha16_l19", z.compress(small_alphabet(5, 128 * KB, 16), 19, True), 128 * KB, note="Huffman literals level 19")
+
+    # ---- sequence-heavy blocks: nbSeq >= 0x7F00 needs the 3-byte count ---------------------------------
+    data = many_sequences(21, 128 * KB)
+    for lvl in (3, 19):
+        add(f"manyseq_l{lvl}", z.compress(data, lvl), len(data), note="many short sequences per block")
+    data = many_sequences(1, 128 * KB, 32, (3,))
+    add("manyseq_longcount_l19", z.compress(data, 19), len(data), note="nbSeq >= 0x7F00: 3-byte sequence count")
+    data = many_sequences(22, 400 * KB)
+    add("manyseq400k_l19_c1", z.compress(data, 19, True), len(data), note="many short sequences, 4 blocks")
+
+    # ---- overlapping matches: period 1..7 and longer, long runs -----------------------------------------
+    for p in (1, 2, 3, 4, 5, 6, 7, 8, 9, 15, 16, 17, 31, 33, 64, 100, 300):
+        n = 70000 + 13 * p
+        add(f"period{p}", z.compress(periodic(p, n, p), 3, True), n, note="offset<matchLength overlap copies",
+            source={"gen": "periodic", "period": p, "seed": p, "n": n})
+    for p in (1, 3, 7, 300):
+        n = 8 << 20
+        add(f"period{p}_8m_l19", z.compress(periodic(p, n, p), 19, True), n, note="8 MB frame of long overlapping matches",
+            source={"gen": "periodic", "period": p, "seed": p, "n": n})
+    # far matches across blocks: same 100 KB chunk repeated with gaps
+    chunk = corpus.text_like(31, 100 * KB)
+    data = chunk + corpus.binary_records(32, 300 * KB) + chunk + noise[:50000] + chunk
+    add("farmatch_l19", z.compress(data, 19, True, window_log=20), len(data), note="matches reaching >400 KB back across blocks")
+
+    # ---- frame-level structure ---------------------------------------------------------------------------
+    f1 = z.compress(corpus.text_like(41, 5000), 3, True)
+    f2 = z.compress(corpus.binary_records(42, 70000), 1)
+    f3 = z.compress(b"", 3)
+    skip = struct.pack("<II", 0x184D2A53, 11) + b"hello world"
+    add("concat3", f1 + f2 + f3, 75000, note="three concatenated frames")
+    add("skippable_mix", skip + f1 + skip + f2 + skip, 75000, note="skippable frames between frames")
+    add("skippable_only", skip, 0, note="only a skippable frame")
+    add("concat_garbage", f1 + b"\x01\x02\x03\x04\x05\x06", 75000, note="garbage after a frame -> srcSize_wrong")
+
+    # ---- dictionaries ----------------------------------------------------------------------------------------
+    recs = records(51, 1200)
+    d = z.train_dictionary(recs[:1000], 16 * KB)
+    manifest_dict_bytes["dict16k"] = d
+    with open(os.path.join(OUT, "dict16k.bin"), "wb") as f:
+        f.write(d)
+    manifest["dicts"]["dict16k"] = {"file": "dict16k.bin", "size": len(d), "sha256": hashlib.sha256(d).hexdigest()}
+    raw = corpus.text_like(52, 8 * KB)
+    manifest_dict_bytes["rawdict8k"] = raw
+    with open(os.path.join(OUT, "rawdict8k.bin"), "wb") as f:
+        f.write(raw)
+    manifest["dicts"]["rawdict8k"] = {"file": "rawdict8k.bin", "size": len(raw), "sha256": hashlib.sha256(raw).hexdigest()}
+    for i in range(24):
+        add(f"rec{i:02d}_dict", z.compress(recs[1000 + i], 3, dictionary=d), 4096, dictionary="dict16k", note="4 KB record, trained dictionary")
+    add("rec_dict_l19_c1", z.compress(b"".join(recs[1100:1140]), 19, True, dictionary=d), 40 * 4096, dictionary="dict16k",
+        note="multi-block frame with dictionary")
+    add("rec_rawdict", z.compress(raw[1000:5000] + corpus.text_like(53, 3000), 3, dictionary=raw), 7000, dictionary="rawdict8k",
+        note="raw-content dictionary")
+    add("rec_nodict_given", z.compress(recs[1000], 3, dictionary=d), 4096, note="dictID set but no dictionary supplied -> dictionary_wrong")
+    add("rec_noid", z.compress(recs[1001], 3, dictionary=d, dict_id=False), 4096, dictionary="dict16k", note="dictionary frame without dictID")
+
+    # ---- corrupted inputs: libzstd's verdict is the expectation ------------------------------------------------
+    base = {
+        "t": z.compress(corpus.text_like(61, 3000), 3, True),
+        "b": z.compress(corpus.binary_records(62, 20000), 19, True),
+        "m": z.compress(many_sequences(63, 6000), 3, True),
+    }
+    rnd = random.Random(71)
+    n_cor = 0
+    for key, fr in base.items():
+        cap = {"t": 3000, "b": 20000, "m": 6000}[key]
+        for cut in (0, 1, 4, 5, 8, 9, 12, len(fr) // 2, len(fr) - 5, len(fr) - 4, len(fr) - 1):
+            add(f"cor_{key}_cut{cut}", fr[:cut], cap, note="truncated")
+            n_cor += 1
+        for _ in range(40):
+            pos = rnd.randrange(len(fr))
+            bad = bytearray(fr)
+            bad[pos] ^= 1 << rnd.randrange(8)
+            add(f"cor_{key}_flip{n_cor}", bytes(bad), cap, note=f"bit flip at {pos}")
+            n_cor += 1
+
+    with open(os.path.join(OUT, "manifest.json"), "w") as f:
+        json.dump(manifest, f, indent=1)
+    total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
+    print(f"{len(manifest['frames'])} fixtures, {total / 1e6:.2f} MB")
+
+
+if __name__ == "__main__":
+    main()

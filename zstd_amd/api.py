@@ -1,0 +1,329 @@
+"""Host-side mirror of the reference's decoder interface over the C ABI of libzstdgpu.so.
+
+Function names and argument meaning follow decompress/zstd_decompressf.pas (ZSTD_decompress,
+ZSTD_decompressDCtx, ZSTD_decompress_usingDDict, ZSTD_getFrameContentSize,
+ZSTD_findFrameCompressedSize, ZSTD_createDDict ...).  Everything here is plumbing: it loads the
+shared library, marshals pointers and sizes, and raises `ZstdError` with the ZSTD_ErrorCode the
+library returned.  There is no CPU fallback: without the built library (or without a GPU) the
+calls fail loudly.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libzstdgpu.so")
+
+CONTENTSIZE_UNKNOWN = (1 << 64) - 1
+CONTENTSIZE_ERROR = (1 << 64) - 2
+NUM_STAGES = 6
+STAGE_NAMES = ("literals", "sequences", "layout", "execute", "checksum", "total")
+
+ERROR_NAMES = {
+    0: "no_error", 1: "GENERIC", 10: "prefix_unknown", 12: "version_unsupported", 14: "frameParameter_unsupported",
+    16: "frameParameter_windowTooLarge", 20: "corruption_detected", 22: "checksum_wrong", 30: "dictionary_corrupted",
+    32: "dictionary_wrong", 64: "memory_allocation", 70: "dstSize_tooSmall", 72: "srcSize_wrong",
+}
+
+
+class ZstdError(Exception):
+    def __init__(self, code: int):
+        self.code = code
+        super().__init__(f"zstd error {code} ({ERROR_NAMES.get(code, '?')})")
+
+
+class FrameIn(ctypes.Structure):
+    _fields_ = [("srcOff", ctypes.c_uint64), ("srcSize", ctypes.c_uint64), ("dstOff", ctypes.c_uint64), ("dstCapacity", ctypes.c_uint64)]
+
+
+class FrameDesc(ctypes.Structure):
+    _fields_ = [("srcOff", ctypes.c_uint64), ("srcSize", ctypes.c_uint64), ("dstOff", ctypes.c_uint64), ("dstCapacity", ctypes.c_uint64),
+                ("contentSize", ctypes.c_uint64), ("windowSize", ctypes.c_uint64), ("firstBlock", ctypes.c_uint32),
+                ("nBlocks", ctypes.c_uint32), ("dictID", ctypes.c_uint32), ("checksumFlag", ctypes.c_uint32),
+                ("checksum", ctypes.c_uint32), ("hostError", ctypes.c_uint32)]
+
+
+class BlockDesc(ctypes.Structure):
+    _fields_ = [("srcOff", ctypes.c_uint64), ("cSize", ctypes.c_uint32), ("origSize", ctypes.c_uint32), ("frameIdx", ctypes.c_uint32),
+                ("blockType", ctypes.c_uint8), ("lastBlock", ctypes.c_uint8), ("hostError", ctypes.c_uint16)]
+
+
+FRAME_STATUS_DTYPE = np.dtype([("errorCode", np.uint32), ("xxh64Low32", np.uint32), ("regenSize", np.uint64)])
+FRAME_IN_DTYPE = np.dtype([("srcOff", np.uint64), ("srcSize", np.uint64), ("dstOff", np.uint64), ("dstCapacity", np.uint64)])
+
+_lib = None
+
+# every symbol include/zstdgpu.h declares
+EXPORTS = (
+    "zstdgpu_isError", "zstdgpu_getErrorCode", "zstdgpu_getErrorName", "zstdgpu_versionNumber",
+    "zstdgpu_create", "zstdgpu_destroy",
+    "zstdgpu_getFrameContentSize", "zstdgpu_findFrameCompressedSize", "zstdgpu_getDictID_fromDict", "zstdgpu_getDictID_fromFrame",
+    "zstdgpu_createDDict", "zstdgpu_freeDDict",
+    "zstdgpu_decompress", "zstdgpu_decompressDCtx", "zstdgpu_decompress_usingDict", "zstdgpu_decompress_usingDDict",
+    "zstdgpu_buildDescriptors", "zstdgpu_batch_create", "zstdgpu_batch_create_from_frames", "zstdgpu_batch_destroy",
+    "zstdgpu_batch_decode", "zstdgpu_batch_status", "zstdgpu_batch_nFrames", "zstdgpu_batch_nBlocks", "zstdgpu_batch_srcBytes",
+    "zstdgpu_batch_scratchBytes", "zstdgpu_batch_set_profiling", "zstdgpu_batch_stage_ms", "zstdgpu_stage_kernel_name",
+    "zstdgpu_xxh64Batch", "zstdgpu_batch_blockInfo", "zstdgpu_batch_copyLiterals", "zstdgpu_batch_copySequences",
+)
+
+
+def lib():
+    """Load libzstdgpu.so and declare its prototypes.  Raises if the library was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`")
+    L = ctypes.CDLL(LIB_PATH)
+    sz, vp, u64, u32, ci = ctypes.c_size_t, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int
+    P = ctypes.POINTER
+
+    def proto(name, res, *args):
+        f = getattr(L, name)
+        f.restype = res
+        f.argtypes = list(args)
+
+    proto("zstdgpu_isError", ctypes.c_uint, sz)
+    proto("zstdgpu_getErrorCode", ctypes.c_uint, sz)
+    proto("zstdgpu_getErrorName", ctypes.c_char_p, sz)
+    proto("zstdgpu_versionNumber", ctypes.c_uint)
+    proto("zstdgpu_create", vp, ci)
+    proto("zstdgpu_destroy", None, vp)
+    proto("zstdgpu_getFrameContentSize", ctypes.c_ulonglong, vp, sz)
+    proto("zstdgpu_findFrameCompressedSize", sz, vp, sz)
+    proto("zstdgpu_getDictID_fromDict", ctypes.c_uint, vp, sz)
+    proto("zstdgpu_getDictID_fromFrame", ctypes.c_uint, vp, sz)
+    proto("zstdgpu_createDDict", vp, vp, vp, sz)
+    proto("zstdgpu_freeDDict", None, vp)
+    proto("zstdgpu_decompress", sz, vp, sz, vp, sz)
+    proto("zstdgpu_decompressDCtx", sz, vp, vp, sz, vp, sz)
+    proto("zstdgpu_decompress_usingDict", sz, vp, vp, sz, vp, sz, vp, sz)
+    proto("zstdgpu_decompress_usingDDict", sz, vp, vp, sz, vp, sz, vp)
+    proto("zstdgpu_buildDescriptors", sz, vp, sz, vp, u32, vp, vp, sz)
+    proto("zstdgpu_batch_create", vp, vp, vp, sz, vp, u32, vp, u32, vp)
+    proto("zstdgpu_batch_create_from_frames", vp, vp, vp, sz, vp, u32, vp)
+    proto("zstdgpu_batch_destroy", None, vp)
+    proto("zstdgpu_batch_decode", sz, vp, vp, vp, vp)
+    proto("zstdgpu_batch_status", sz, vp, vp)
+    proto("zstdgpu_batch_nFrames", u32, vp)
+    proto("zstdgpu_batch_nBlocks", u32, vp)
+    proto("zstdgpu_batch_srcBytes", u64, vp)
+    proto("zstdgpu_batch_scratchBytes", u64, vp)
+    proto("zstdgpu_batch_set_profiling", None, vp, ci)
+    proto("zstdgpu_batch_stage_ms", sz, vp, P(ctypes.c_float))
+    proto("zstdgpu_stage_kernel_name", ctypes.c_char_p, ci)
+    proto("zstdgpu_xxh64Batch", sz, vp, vp, vp, vp, u32, vp)
+    proto("zstdgpu_batch_blockInfo", sz, vp, u32, P(u32), P(u32), P(u64), P(u32))
+    proto("zstdgpu_batch_copyLiterals", sz, vp, vp, u32, vp, sz)
+    proto("zstdgpu_batch_copySequences", sz, vp, u32, vp, sz)
+    _lib = L
+    return L
+
+
+def _check(r: int) -> int:
+    L = lib()
+    if L.zstdgpu_isError(r):
+        raise ZstdError(L.zstdgpu_getErrorCode(r))
+    return r
+
+
+# --------------------------------------------------------------------------- host-side queries
+def ZSTD_getFrameContentSize(src: bytes) -> int:
+    return lib().zstdgpu_getFrameContentSize(src, len(src))
+
+
+def ZSTD_findFrameCompressedSize(src: bytes) -> int:
+    return _check(lib().zstdgpu_findFrameCompressedSize(src, len(src)))
+
+
+def ZSTD_getDictID_fromDict(d: bytes) -> int:
+    return lib().zstdgpu_getDictID_fromDict(d, len(d))
+
+
+def ZSTD_getDictID_fromFrame(src: bytes) -> int:
+    return lib().zstdgpu_getDictID_fromFrame(src, len(src))
+
+
+# --------------------------------------------------------------------------- context / dictionary
+class DCtx:
+    """ZSTD_DCtx stand-in: one per GPU, not re-entrant."""
+
+    def __init__(self, device: int = 0):
+        self.h = lib().zstdgpu_create(device)
+        if not self.h:
+            raise RuntimeError(f"zstdgpu_create({device}) failed: no usable GPU")
+        self.device = device
+
+    def close(self):
+        if self.h:
+            lib().zstdgpu_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DDict:
+    """ZSTD_DDict stand-in: dictionary copied to the GPU, entropy tables digested there once."""
+
+    def __init__(self, dctx: DCtx, dictionary: bytes):
+        self.dctx = dctx
+        self.h = lib().zstdgpu_createDDict(dctx.h, dictionary, len(dictionary))
+        if not self.h:
+            raise ZstdError(64)
+
+    def close(self):
+        if self.h:
+            lib().zstdgpu_freeDDict(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# --------------------------------------------------------------------------- one-shot drop-ins (host buffers)
+def ZSTD_decompressDCtx(dctx: DCtx, src: bytes, dstCapacity: int) -> bytes:
+    out = ctypes.create_string_buffer(max(dstCapacity, 1))
+    r = _check(lib().zstdgpu_decompressDCtx(dctx.h, out, dstCapacity, src, len(src)))
+    return out.raw[:r]
+
+
+def ZSTD_decompress(src: bytes, dstCapacity: int) -> bytes:
+    out = ctypes.create_string_buffer(max(dstCapacity, 1))
+    r = _check(lib().zstdgpu_decompress(out, dstCapacity, src, len(src)))
+    return out.raw[:r]
+
+
+def ZSTD_decompress_usingDict(dctx: DCtx, src: bytes, dstCapacity: int, dictionary: bytes) -> bytes:
+    out = ctypes.create_string_buffer(max(dstCapacity, 1))
+    r = _check(lib().zstdgpu_decompress_usingDict(dctx.h, out, dstCapacity, src, len(src), dictionary, len(dictionary or b"")))
+    return out.raw[:r]
+
+
+def ZSTD_decompress_usingDDict(dctx: DCtx, src: bytes, dstCapacity: int, ddict: DDict) -> bytes:
+    out = ctypes.create_string_buffer(max(dstCapacity, 1))
+    r = _check(lib().zstdgpu_decompress_usingDDict(dctx.h, out, dstCapacity, src, len(src), ddict.h if ddict else None))
+    return out.raw[:r]
+
+
+# --------------------------------------------------------------------------- batches (device buffers)
+def build_descriptors(host_src: np.ndarray, frames_in: np.ndarray):
+    """C mirror of the host descriptor builder.  Returns (FrameDesc array, BlockDesc array)."""
+    L = lib()
+    n = len(frames_in)
+    fin = np.ascontiguousarray(frames_in, dtype=FRAME_IN_DTYPE)
+    fds = (FrameDesc * max(n, 1))()
+    nb = _check(L.zstdgpu_buildDescriptors(host_src.ctypes.data, host_src.nbytes, fin.ctypes.data, n, fds, None, 0))
+    bds = (BlockDesc * max(nb, 1))()
+    nb2 = _check(L.zstdgpu_buildDescriptors(host_src.ctypes.data, host_src.nbytes, fin.ctypes.data, n, fds, bds, nb))
+    assert nb2 == nb
+    return fds, bds, nb
+
+
+class Batch:
+    """A prepared batch of independent frames: descriptors and scratch live on the GPU, `decode`
+    launches the stage chain on device buffers and allocates nothing."""
+
+    def __init__(self, dctx: DCtx, host_src: np.ndarray, frames_in: np.ndarray, ddict: DDict = None, via_descriptors: bool = False):
+        L = lib()
+        self.dctx, self.ddict = dctx, ddict
+        self.n = len(frames_in)
+        host_src = np.ascontiguousarray(host_src, dtype=np.uint8)
+        fin = np.ascontiguousarray(frames_in, dtype=FRAME_IN_DTYPE)
+        dd = ddict.h if ddict else None
+        if via_descriptors:
+            fds, bds, nb = build_descriptors(host_src, fin)
+            self.h = L.zstdgpu_batch_create(dctx.h, host_src.ctypes.data, host_src.nbytes, fds, self.n, bds, nb, dd)
+        else:
+            self.h = L.zstdgpu_batch_create_from_frames(dctx.h, host_src.ctypes.data, host_src.nbytes, fin.ctypes.data, self.n, dd)
+        if not self.h:
+            raise ZstdError(64)
+
+    @property
+    def n_blocks(self):
+        return lib().zstdgpu_batch_nBlocks(self.h)
+
+    @property
+    def src_bytes(self):
+        return lib().zstdgpu_batch_srcBytes(self.h)
+
+    @property
+    def scratch_bytes(self):
+        return lib().zstdgpu_batch_scratchBytes(self.h)
+
+    def decode(self, dev_src_ptr: int, dev_dst_ptr: int, stream: int = 0):
+        _check(lib().zstdgpu_batch_decode(self.h, dev_src_ptr, dev_dst_ptr, stream or None))
+
+    def status(self) -> np.ndarray:
+        st = np.zeros(max(self.n, 1), dtype=FRAME_STATUS_DTYPE)
+        _check(lib().zstdgpu_batch_status(self.h, st.ctypes.data))
+        return st[: self.n]
+
+    def set_profiling(self, on: bool):
+        lib().zstdgpu_batch_set_profiling(self.h, int(on))
+
+    def stage_ms(self):
+        ms = (ctypes.c_float * NUM_STAGES)()
+        _check(lib().zstdgpu_batch_stage_ms(self.h, ms))
+        return list(ms)
+
+    def block_info(self, bi: int):
+        L = lib()
+        a, b, c, d = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint64(), ctypes.c_uint32()
+        _check(L.zstdgpu_batch_blockInfo(self.h, bi, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c), ctypes.byref(d)))
+        return dict(litSize=a.value, nbSeq=b.value, regen=c.value, error=d.value)
+
+    def literals(self, dev_src_ptr: int, bi: int) -> bytes:
+        out = ctypes.create_string_buffer(1 << 17)
+        r = _check(lib().zstdgpu_batch_copyLiterals(self.h, dev_src_ptr, bi, out, 1 << 17))
+        return out.raw[:r]
+
+    def sequences(self, bi: int) -> np.ndarray:
+        cap = 0x7F00 + 0xFFFF + 1
+        out = np.zeros((cap, 3), dtype=np.uint32)
+        r = _check(lib().zstdgpu_batch_copySequences(self.h, bi, out.ctypes.data, cap))
+        return out[:r].copy()
+
+    def close(self):
+        if self.h:
+            lib().zstdgpu_batch_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def xxh64_batch(dctx: DCtx, dev_base_ptr: int, offsets, lengths) -> np.ndarray:
+    off = np.ascontiguousarray(offsets, dtype=np.uint64)
+    ln = np.ascontiguousarray(lengths, dtype=np.uint64)
+    out = np.zeros(len(off), dtype=np.uint64)
+    _check(lib().zstdgpu_xxh64Batch(dctx.h, dev_base_ptr, off.ctypes.data, ln.ctypes.data, len(off), out.ctypes.data))
+    return out
+
+
+def pack_frames(frames, capacities=None, align: int = 16):
+    """Concatenate compressed frames into one source buffer (each frame `align`-aligned) and lay
+    their outputs out back to back.  Returns (host_src uint8 array, FrameIn array, dst_bytes)."""
+    n = len(frames)
+    fin = np.zeros(n, dtype=FRAME_IN_DTYPE)
+    so = do = 0
+    for i, fr in enumerate(frames):
+        cap = len(fr) if capacities is None else capacities[i]
+        fin[i] = (so, len(fr), do, cap)
+        so += (len(fr) + align - 1) // align * align
+        do += (cap + align - 1) // align * align
+    src = np.zeros(so + 64, dtype=np.uint8)
+    for i, fr in enumerate(frames):
+        o = int(fin[i]["srcOff"])
+        src[o:o + len(fr)] = np.frombuffer(fr, dtype=np.uint8)
+    return src, fin, do + 64

@@ -1,0 +1,957 @@
+// gfx950 kernels of the batched zstd decoder.
+//
+// Stage map (reference routine each stage must reproduce, file:line in the reference tree):
+//   k_literals   HUF_readStats_body (common/entropy_common.pas:311-392), FSE_decompress_wksp_body
+//                (common/fse_decompress.pas:341-383), HUF_readDTableX1_wksp (decompress/huf_decompress.pas:133-285),
+//                HUF_decompress1X1/4X1_usingDTable_internal_body (:350-559)
+//   k_sequences  FSE_readNCount_body (common/entropy_common.pas:83-256), ZSTD_buildFSETable_body /
+//                ZSTD_buildSeqTable (decompress/zstd_decompress_block.pas:436-688), ZSTD_decodeSequence (:1083-1230)
+//   k_layout     the op/rep hand-over between blocks of ZSTD_decompressFrame (decompress/zstd_decompressf.pas:772-808)
+//   k_execute    ZSTD_execSequence / ZSTD_execSequenceEnd (decompress/zstd_decompress_block.pas:896-1039), last
+//                literals (:1308-1317), ZSTD_copyRawBlock / ZSTD_setRleBlock (decompress/zstd_decompressf.pas:699-731)
+//   k_checksum   XXH64 (common/xxhash.pas:393-488) + the frame verdict of ZSTD_decompressFrame (:810-828)
+//   k_digest_dict ZSTD_loadDEntropy (decompress/zstd_decompressf.pas:1261-1356)
+//
+// All arithmetic is integer; wave = 64 lanes; every workgroup is a single wave, so lanes of a
+// workgroup run in lockstep and exchange data through LDS with a fence only.
+#include <hip/hip_runtime.h>
+#include "zstdgpu_internal.h"
+
+namespace zg {
+namespace {
+
+#define DEVI __device__ __forceinline__
+
+// ---------------------------------------------------------------- small helpers
+DEVI uint32_t hb32(uint32_t v) { return 31u - (uint32_t)__builtin_clz(v); }
+
+// orders LDS and global accesses of the lanes of this (single-wave) workgroup
+DEVI void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+DEVI uint64_t ld_u64(const uint8_t* p)
+{
+    uint64_t v;
+    __builtin_memcpy(&v, p, 8);
+    return v;
+}
+// little-endian 32-bit read at byte index i of a buffer of `size` bytes, zero beyond the end
+DEVI uint32_t rd32z(const uint8_t* p, uint32_t size, uint32_t i)
+{
+    uint32_t v = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        if (i + k < size) v |= (uint32_t)p[i + k] << (8 * k);
+    return v;
+}
+
+// Backward bit reader (BIT_DStream_t, common/bitstream.pas:40-51, :206-398) kept as a logical bit
+// position: `left()` bits of the stream remain unread.  The 64-bit window is re-read from global
+// memory at byte granularity so that at most 7 bits of it are already consumed.
+struct BitR {
+    const uint8_t* start;
+    uint64_t w;
+    int c;      // bits of w consumed
+    int base;   // left() + c, constant between refills
+
+    DEVI void refill_at(int bitsLeft)
+    {
+        int const byteIdx = (bitsLeft - 57) >> 3;   // may be -8..-1 near the stream start: frame/block headers precede every stream
+        w = ld_u64(start + byteIdx);
+        c = 8 * byteIdx + 64 - bitsLeft;
+        base = bitsLeft + c;
+    }
+    // BIT_initDStream: false when the stream is empty or its last byte carries no end mark
+    DEVI bool init(const uint8_t* s, uint32_t size)
+    {
+        start = s; w = 0; c = 0; base = -1;
+        if (size == 0) return false;
+        uint32_t const last = s[size - 1];
+        if (last == 0) return false;
+        refill_at((int)(size * 8) - (int)(8 - hb32(last)));
+        return true;
+    }
+    DEVI int left() const { return base - c; }
+    DEVI void refill()
+    {
+        int const l = left();
+        if (l >= 0) refill_at(l);
+    }
+    // read n <= 32 bits; caller guarantees c + n <= 64 on valid streams (garbage, but in range, otherwise)
+    DEVI uint32_t read(uint32_t n)
+    {
+        uint32_t const v = (uint32_t)(((w << (c & 63)) >> 1) >> (63 - n));
+        c += (int)n;
+        return v;
+    }
+};
+
+// ---------------------------------------------------------------- FSE_readNCount (entropy_common.pas:83-256)
+constexpr uint32_t kFail = 0xFFFFFFFFu;
+
+// norm[] receives maxSV+1 entries.  Returns the header size in bytes or kFail.
+template <typename NormPtr>
+DEVI uint32_t dev_readNCount(NormPtr norm, uint32_t& maxSV, uint32_t& tableLog, const uint8_t* src, uint32_t hbSize)
+{
+    int const iend = hbSize < 8 ? 8 : (int)hbSize;    // short headers are decoded from a zero-padded copy (:100-113)
+    int ip = 0;
+    uint32_t const maxSV1 = maxSV + 1;
+    for (uint32_t s = 0; s < maxSV1; s++) norm[s] = 0;
+    uint32_t bitStream = rd32z(src, hbSize, 0);
+    int nbBits = (int)(bitStream & 0xF) + 5;
+    if (nbBits > 15) return kFail;
+    bitStream >>= 4;
+    int bitCount = 4;
+    tableLog = (uint32_t)nbBits;
+    int remaining = (1 << nbBits) + 1;
+    int threshold = 1 << nbBits;
+    nbBits++;
+    uint32_t charnum = 0;
+    bool previous0 = false;
+    for (;;) {
+        if (previous0) {
+            int repeats = (int)(__builtin_ctz(~bitStream | 0x80000000u) >> 1);
+            while (repeats >= 12) {
+                charnum += 3 * 12;
+                if (ip <= iend - 7) ip += 3;
+                else { bitCount -= 8 * (iend - 7 - ip); bitCount &= 31; ip = iend - 4; }
+                bitStream = rd32z(src, hbSize, (uint32_t)ip) >> bitCount;
+                repeats = (int)(__builtin_ctz(~bitStream | 0x80000000u) >> 1);
+                if (charnum >= maxSV1) break;   // already an error; leave the inner loop early
+            }
+            charnum += 3 * (uint32_t)repeats;
+            bitStream >>= 2 * repeats;
+            bitCount += 2 * repeats;
+            charnum += bitStream & 3;
+            bitCount += 2;
+            if (charnum >= maxSV1) break;
+            if ((ip <= iend - 7) || (ip + (bitCount >> 3) <= iend - 4)) { ip += bitCount >> 3; bitCount &= 7; }
+            else { bitCount -= 8 * (iend - 4 - ip); bitCount &= 31; ip = iend - 4; }
+            bitStream = rd32z(src, hbSize, (uint32_t)ip) >> bitCount;
+        }
+        {
+            int const max = (2 * threshold - 1) - remaining;
+            int count;
+            if ((bitStream & (uint32_t)(threshold - 1)) < (uint32_t)max) { count = (int)(bitStream & (uint32_t)(threshold - 1)); bitCount += nbBits - 1; }
+            else { count = (int)(bitStream & (uint32_t)(2 * threshold - 1)); if (count >= threshold) count -= max; bitCount += nbBits; }
+            count--;
+            if (count >= 0) remaining -= count; else remaining += count;
+            norm[charnum++] = (int16_t)count;
+            previous0 = (count == 0);
+            if (remaining < threshold) {
+                if (remaining <= 1) break;
+                nbBits = (int)hb32((uint32_t)remaining) + 1;
+                threshold = 1 << (nbBits - 1);
+            }
+            if (charnum >= maxSV1) break;
+            if ((ip <= iend - 7) || (ip + (bitCount >> 3) <= iend - 4)) { ip += bitCount >> 3; bitCount &= 7; }
+            else { bitCount -= 8 * (iend - 4 - ip); bitCount &= 31; ip = iend - 4; }
+            bitStream = rd32z(src, hbSize, (uint32_t)ip) >> bitCount;
+        }
+    }
+    if (remaining != 1) return kFail;
+    if (charnum > maxSV1) return kFail;
+    if (bitCount > 32) return kFail;
+    maxSV = charnum - 1;
+    ip += (bitCount + 7) >> 3;
+    if ((uint32_t)ip > hbSize) return kFail;
+    return (uint32_t)ip;
+}
+
+// ---------------------------------------------------------------- Huffman weights
+// Scratch layout inside a job's (still unused) table area while the weights are decoded.
+constexpr uint32_t kWNormOff = 0;       // int16 norm[256]
+constexpr uint32_t kWNextOff = 512;     // uint16 symbolNext[256]
+constexpr uint32_t kWTabOff = 1024;     // uint32 dtable[64]  {newState<<16 | nbBits<<8 | symbol}
+
+// FSE_decompress_wksp_body (fse_decompress.pas:341-383) for the <=255 Huffman weights: header, table
+// (FSE_buildDTable_internal, :40-176), two-state decode (FSE_decompress_usingDTable_generic, :242-316).
+// Returns the number of weights or kFail.
+template <typename BytePtr>
+DEVI uint32_t dev_fse_weights(BytePtr weights, uint32_t maxOut, const uint8_t* src, uint32_t srcSize, uint8_t* scratch)
+{
+    int16_t* const norm = (int16_t*)(scratch + kWNormOff);
+    uint16_t* const symNext = (uint16_t*)(scratch + kWNextOff);
+    uint32_t* const dt = (uint32_t*)(scratch + kWTabOff);
+    uint32_t maxSV = 255, tableLog = 0;
+    uint32_t const hSize = dev_readNCount(norm, maxSV, tableLog, src, srcSize);
+    if (hSize == kFail) return kFail;
+    if (tableLog > 6) return kFail;
+    uint32_t const tableSize = 1u << tableLog;
+    uint32_t highThreshold = tableSize - 1;
+    for (uint32_t s = 0; s <= maxSV; s++) {
+        if (norm[s] == -1) { dt[highThreshold--] = s; symNext[s] = 1; }
+        else symNext[s] = (uint16_t)norm[s];
+    }
+    {
+        uint32_t const mask = tableSize - 1, step = (tableSize >> 1) + (tableSize >> 3) + 3;
+        uint32_t pos = 0;
+        for (uint32_t s = 0; s <= maxSV; s++) {
+            int const n = norm[s];
+            for (int i = 0; i < n; i++) {
+                dt[pos] = s;
+                pos = (pos + step) & mask;
+                while (pos > highThreshold) pos = (pos + step) & mask;
+            }
+        }
+        if (pos != 0) return kFail;
+    }
+    for (uint32_t u = 0; u < tableSize; u++) {
+        uint32_t const sym = dt[u];
+        uint32_t const ns = symNext[sym]++;
+        uint32_t const nb = tableLog - hb32(ns);
+        dt[u] = (((ns << nb) - tableSize) << 16) | (nb << 8) | sym;
+    }
+    BitR br;
+    if (!br.init(src + hSize, srcSize - hSize)) return kFail;
+    uint32_t s1 = br.read(tableLog); br.refill();
+    uint32_t s2 = br.read(tableLog); br.refill();
+    if (br.left() < 0) return kFail;   // states alone overran the stream: upstream decodes garbage here, never a valid header
+    uint32_t n = 0;
+    for (;;) {
+        if (n + 2 > maxOut) return kFail;
+        { uint32_t const d = dt[s1]; weights[n++] = (uint8_t)d; s1 = (d >> 16) + br.read((d >> 8) & 0xFF); }
+        if (br.left() < 0) { weights[n++] = (uint8_t)dt[s2]; break; }
+        br.refill();
+        if (n + 2 > maxOut) return kFail;
+        { uint32_t const d = dt[s2]; weights[n++] = (uint8_t)d; s2 = (d >> 16) + br.read((d >> 8) & 0xFF); }
+        if (br.left() < 0) { weights[n++] = (uint8_t)dt[s1]; break; }
+        br.refill();
+    }
+    return n;
+}
+
+// HUF_readStats_body (entropy_common.pas:311-392) followed by the rank scan of
+// HUF_readDTableX1_wksp (huf_decompress.pas:133-285): fills weights[0..nbSymbols) and pos[n] = first
+// table cell of symbol n.  Returns header bytes consumed or kFail.  Runs on one lane.
+template <typename BytePtr, typename PosPtr, typename RankPtr>
+DEVI uint32_t dev_huf_read_table_desc(const uint8_t* src, uint32_t srcSize, BytePtr weights, PosPtr pos, RankPtr rank,
+                                      uint8_t* scratch, uint32_t& nbSymbols, uint32_t& tableLog)
+{
+    if (srcSize == 0) return kFail;
+    uint32_t iSize = src[0];
+    uint32_t oSize;
+    if (iSize >= 128) {
+        oSize = iSize - 127;
+        iSize = (oSize + 1) / 2;
+        if (iSize + 1 > srcSize) return kFail;
+        for (uint32_t n = 0; n < oSize; n += 2) {
+            uint32_t const b = src[1 + n / 2];
+            weights[n] = (uint8_t)(b >> 4);
+            weights[n + 1] = (uint8_t)(b & 15);
+        }
+    } else {
+        if (iSize + 1 > srcSize) return kFail;
+        oSize = dev_fse_weights(weights, 255, src + 1, iSize, scratch);
+        if (oSize == kFail) return kFail;
+    }
+    for (int r = 0; r <= 12; r++) rank[r] = 0;
+    uint32_t weightTotal = 0;
+    for (uint32_t n = 0; n < oSize; n++) {
+        uint32_t const w = weights[n];
+        if (w >= 12) return kFail;
+        rank[w] = rank[w] + 1;
+        weightTotal += (1u << w) >> 1;
+    }
+    if (weightTotal == 0) return kFail;
+    tableLog = hb32(weightTotal) + 1;
+    if (tableLog > 12) return kFail;
+    {
+        uint32_t const rest = (1u << tableLog) - weightTotal;
+        uint32_t const lastWeight = hb32(rest) + 1;
+        if ((1u << hb32(rest)) != rest) return kFail;
+        weights[oSize] = (uint8_t)lastWeight;
+        rank[lastWeight] = rank[lastWeight] + 1;
+    }
+    if (rank[1] < 2 || (rank[1] & 1)) return kFail;
+    nbSymbols = oSize + 1;
+    {   // rank[w] := first cell of weight class w
+        uint32_t next = 0;
+        for (uint32_t n = 1; n < tableLog + 1; n++) { uint32_t const cur = next; next += rank[n] << (n - 1); rank[n] = cur; }
+    }
+    for (uint32_t n = 0; n < nbSymbols; n++) {
+        uint32_t const w = weights[n];
+        uint32_t const len = (1u << w) >> 1;
+        pos[n] = (uint16_t)rank[w];
+        rank[w] = rank[w] + len;
+    }
+    return iSize + 1;
+}
+
+// ---------------------------------------------------------------- stage 0: literals
+constexpr int kHufLanes = 8;                 // lanes per literal job (4 streams + helpers for the table fill)
+constexpr int kHufJobs = 64 / kHufLanes;     // jobs per wave
+constexpr uint32_t kHufTabBytes = 8192;      // 2^12 cells of {byte, nbBits}
+constexpr uint32_t kHufAuxBytes = 1024;      // weights[256] | pos[256] u16 | rank[13] u32
+constexpr uint32_t kHufJobBytes = kHufTabBytes + kHufAuxBytes;
+
+// one backward stream -> `n` bytes at `out` (HUF_decodeStreamX1 + the BIT_endOfDStream check, huf_decompress.pas:301-349, :553-555)
+DEVI bool huf_decode_stream(const uint16_t* cells, uint32_t tableLog, const uint8_t* s, uint32_t size, uint8_t* out, uint32_t n)
+{
+    BitR br;
+    if (!br.init(s, size)) return false;
+    uint32_t const shift = 64 - tableLog;
+    for (uint32_t i = 0; i < n; i++) {
+        if (br.c > 52) {
+            if (br.left() < 0) return false;
+            br.refill();
+        }
+        uint32_t const idx = (uint32_t)((br.w << br.c) >> shift);
+        uint32_t const cell = cells[idx];
+        br.c += (int)(cell >> 8);
+        out[i] = (uint8_t)cell;
+    }
+    return br.left() == 0;
+}
+
+__global__ __launch_bounds__(64) void k_literals(BatchParams p)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kHufJobs * kHufJobBytes];
+    uint32_t const lane = threadIdx.x;
+    uint32_t const sub = lane / kHufLanes, sl = lane % kHufLanes;
+    uint32_t const job = blockIdx.x * kHufJobs + sub;
+    if (job >= p.nLitJobs) return;
+    uint32_t const b = p.litJobs[job];
+    DevBlock const blk = p.blocks[b];
+    uint8_t* const tab = lds + sub * kHufJobBytes;
+    uint16_t* const cells = (uint16_t*)tab;
+    uint8_t* const weights = tab + kHufTabBytes;
+    uint16_t* const pos = (uint16_t*)(tab + kHufTabBytes + 256);
+    uint32_t* const rank = (uint32_t*)(tab + kHufTabBytes + 768);
+
+    uint32_t err = 0, tableLog = 0, nbSymbols = 0, hSize = 0;
+    bool const fromDict = (blk.hufSrc == SRC_DICT);
+    if (sl == 0) {
+        if (blk.litType == SET_COMPRESSED && !blk.singleStream && (blk.litSize == 0 || blk.litCSize == 0)) err = E_corruption;   // huf_decompress.pas:1421-1424
+        else if (blk.hufSrc == SRC_NONE) err = E_corruption;
+        else if (fromDict) tableLog = p.dict->hufLog;
+        else {
+            DevBlock const sb = (blk.hufSrc == (int32_t)b) ? blk : p.blocks[blk.hufSrc];
+            uint32_t const r = dev_huf_read_table_desc(p.src + sb.srcOff + sb.litHdrSize, sb.litCSize, weights, pos, rank, tab, nbSymbols, tableLog);
+            if (r == kFail) err = E_corruption;
+            else {
+                hSize = r;
+                if (blk.litType == SET_COMPRESSED && hSize >= blk.litCSize) err = E_corruption;   // huf_decompress.pas:1394, :1349
+            }
+        }
+    }
+    wave_sync();
+    uint32_t const lead = sub * kHufLanes;
+    err = __shfl(err, lead); tableLog = __shfl(tableLog, lead); nbSymbols = __shfl(nbSymbols, lead); hSize = __shfl(hSize, lead);
+
+    bool ok = (err == 0);
+    if (ok) {
+        // table fill (HUF_readDTableX1_wksp second half): cell = {symbol, nbBits = tableLog + 1 - weight}
+        if (fromDict) {
+            uint32_t const n = 1u << tableLog;
+            for (uint32_t u = sl; u < n; u += kHufLanes) cells[u] = p.dict->huf[u];
+        } else {
+            for (uint32_t n = sl; n < nbSymbols; n += kHufLanes) {
+                uint32_t const w = weights[n];
+                if (w) {
+                    uint32_t const len = (1u << w) >> 1;
+                    uint32_t const start = pos[n];
+                    uint16_t const cell = (uint16_t)(n | ((tableLog + 1 - w) << 8));
+                    for (uint32_t u = 0; u < len; u++) cells[start + u] = cell;
+                }
+            }
+        }
+    }
+    wave_sync();
+    if (ok) {
+        uint32_t const tabHdr = (blk.litType == SET_COMPRESSED) ? hSize : 0;
+        const uint8_t* const cs = p.src + blk.srcOff + blk.litHdrSize + tabHdr;
+        uint32_t const csize = blk.litCSize - tabHdr;
+        uint8_t* const out = p.litBuf + blk.litBufOff;
+        if (blk.singleStream) {
+            if (sl == 0) ok = huf_decode_stream(cells, tableLog, cs, csize, out, blk.litSize);
+        } else {
+            // 4 streams: 6-byte jump table, segment = (litSize+3)/4 (huf_decompress.pas:406-421)
+            if (csize < 10) ok = false;
+            else {
+                uint32_t const l1 = cs[0] | (cs[1] << 8), l2 = cs[2] | (cs[3] << 8), l3 = cs[4] | (cs[5] << 8);
+                uint32_t const seg = (blk.litSize + 3) / 4;
+                if (l1 + l2 + l3 + 6 > csize || 3 * seg > blk.litSize) ok = false;
+                else if (sl < 4) {
+                    uint32_t const l4 = csize - 6 - l1 - l2 - l3;
+                    uint32_t const so = 6 + (sl > 0 ? l1 : 0) + (sl > 1 ? l2 : 0) + (sl > 2 ? l3 : 0);
+                    uint32_t const ssz = sl == 0 ? l1 : sl == 1 ? l2 : sl == 2 ? l3 : l4;
+                    uint32_t const oo = sl * seg;
+                    uint32_t const on = sl < 3 ? seg : blk.litSize - 3 * seg;
+                    ok = huf_decode_stream(cells, tableLog, cs + so, ssz, out + oo, on);
+                }
+            }
+        }
+    }
+    unsigned long long const bad = __ballot(!ok);
+    if (sl == 0) {
+        uint32_t const mine = (uint32_t)((bad >> lead) & ((1u << kHufLanes) - 1));
+        p.state[b].litErr = err ? err : (mine ? (uint32_t)E_corruption : 0u);
+    }
+}
+
+// ---------------------------------------------------------------- sequence tables
+// Packed decoding cell of a sequence table: nextState base (9 bits) | nbBits (4) << 9 | symbol code (6) << 13.
+// Base value and extra-bit count of a code come from small side tables (LL/ML) or arithmetic (OF).
+DEVI uint32_t seq_cell(uint32_t nextState, uint32_t nbBits, uint32_t code) { return nextState | (nbBits << 9) | (code << 13); }
+
+__constant__ uint32_t c_LL_base[36] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18, 20, 22, 24, 28, 32, 40,
+                                       48, 64, 0x80, 0x100, 0x200, 0x400, 0x800, 0x1000, 0x2000, 0x4000, 0x8000, 0x10000};
+__constant__ uint8_t c_LL_bits[36] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 3, 3,
+                                      4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
+__constant__ uint32_t c_ML_base[53] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26,
+                                       27, 28, 29, 30, 31, 32, 33, 34, 35, 37, 39, 41, 43, 47, 51, 59, 67, 83, 99, 0x83, 0x103,
+                                       0x203, 0x403, 0x803, 0x1003, 0x2003, 0x4003, 0x8003, 0x10003};
+__constant__ uint8_t c_ML_bits[53] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+                                      0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 3, 3, 4, 4, 5, 7, 8, 9, 10, 11,
+                                      12, 13, 14, 15, 16};
+__constant__ int16_t c_LL_defaultNorm[36] = {4, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2,
+                                             2, 3, 2, 1, 1, 1, 1, 1, -1, -1, -1, -1};
+__constant__ int16_t c_ML_defaultNorm[53] = {1, 4, 3, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1,
+                                             1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1,
+                                             -1, -1, -1, -1, -1};
+__constant__ int16_t c_OF_defaultNorm[29] = {1, 1, 1, 1, 1, 1, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1};
+
+enum { T_LL = 0, T_OF = 1, T_ML = 2 };
+DEVI uint32_t tbl_max(int t) { return t == T_LL ? 35u : t == T_OF ? 31u : 52u; }
+DEVI uint32_t tbl_maxLog(int t) { return t == T_OF ? 8u : 9u; }
+
+// ZSTD_buildFSETable_body (zstd_decompress_block.pas:436-583) into packed cells.  `norm` holds maxSV+1 counts.
+template <typename CellPtr, typename NormPtr, typename NextPtr>
+DEVI void dev_build_seq_table(CellPtr cells, NormPtr norm, NextPtr symNext, uint32_t maxSV, uint32_t tableLog)
+{
+    uint32_t const tableSize = 1u << tableLog;
+    uint32_t highThreshold = tableSize - 1;
+    for (uint32_t s = 0; s <= maxSV; s++) {
+        if (norm[s] == -1) { cells[highThreshold--] = s; symNext[s] = 1; }
+        else symNext[s] = (uint16_t)norm[s];
+    }
+    uint32_t const mask = tableSize - 1, step = (tableSize >> 1) + (tableSize >> 3) + 3;
+    uint32_t pos = 0;
+    for (uint32_t s = 0; s <= maxSV; s++) {
+        int const n = norm[s];
+        for (int i = 0; i < n; i++) {
+            cells[pos] = s;
+            pos = (pos + step) & mask;
+            while (pos > highThreshold) pos = (pos + step) & mask;
+        }
+    }
+    for (uint32_t u = 0; u < tableSize; u++) {
+        uint32_t const sym = cells[u];
+        uint32_t const ns = symNext[sym];
+        symNext[sym] = (uint16_t)(ns + 1);
+        uint32_t const nb = tableLog - hb32(ns);
+        cells[u] = seq_cell((ns << nb) - tableSize, nb, sym);
+    }
+}
+
+// Build table `t` from a description of type `type` at `ptr` (`avail` bytes left in the block):
+// ZSTD_buildSeqTable (zstd_decompress_block.pas:626-688) without the repeat arm.
+// Returns bytes consumed or kFail; sets log.
+template <typename CellPtr, typename NormPtr, typename NextPtr>
+DEVI uint32_t dev_build_from_desc(int t, uint32_t type, const uint8_t* ptr, uint32_t avail, CellPtr cells, NormPtr norm, NextPtr symNext, uint32_t& log)
+{
+    if (type == SET_RLE) {
+        if (avail < 1) return kFail;
+        uint32_t const sym = ptr[0];
+        if (sym > tbl_max(t)) return kFail;
+        cells[0] = seq_cell(0, 0, sym);
+        log = 0;
+        return 1;
+    }
+    if (type == SET_BASIC) {   // predefined distributions (zstd_internal.pas:64-99), tables of zstd_decompress_block.pas:29-125
+        uint32_t maxSV;
+        if (t == T_LL) { maxSV = 35; log = 6; for (uint32_t s = 0; s <= maxSV; s++) norm[s] = c_LL_defaultNorm[s]; }
+        else if (t == T_OF) { maxSV = 28; log = 5; for (uint32_t s = 0; s <= maxSV; s++) norm[s] = c_OF_defaultNorm[s]; }
+        else { maxSV = 52; log = 6; for (uint32_t s = 0; s <= maxSV; s++) norm[s] = c_ML_defaultNorm[s]; }
+        dev_build_seq_table(cells, norm, symNext, maxSV, log);
+        return 0;
+    }
+    // SET_COMPRESSED
+    uint32_t maxSV = tbl_max(t), tableLog = 0;
+    uint32_t const h = dev_readNCount(norm, maxSV, tableLog, ptr, avail);
+    if (h == kFail) return kFail;
+    if (tableLog > tbl_maxLog(t)) return kFail;
+    dev_build_seq_table(cells, norm, symNext, maxSV, tableLog);
+    log = tableLog;
+    return h;
+}
+
+// Size in bytes of the description of table `t` of block `sb` at payload offset `o` (used to walk to a later description).
+template <typename NormPtr>
+DEVI uint32_t dev_desc_size(int t, uint32_t type, const uint8_t* payload, uint32_t o, uint32_t cSize, NormPtr norm)
+{
+    if (type == SET_RLE) return o < cSize ? 1 : kFail;
+    if (type != SET_COMPRESSED) return 0;
+    if (o > cSize) return kFail;
+    uint32_t maxSV = tbl_max(t), tableLog = 0;
+    return dev_readNCount(norm, maxSV, tableLog, payload + o, cSize - o);
+}
+
+// ---------------------------------------------------------------- stage 1: sequences
+constexpr int kSeqJobs = 4;                 // jobs per wave; the job runs on the first lane of its 16-lane group
+constexpr uint32_t kSeqJobWords = 512 + 512 + 256 + 64;   // LL | ML | OF cells + {norm[64] i16, symNext[64] u16}
+constexpr uint32_t kRepIdxShift = 29;
+
+DEVI uint32_t rep_dec1(uint32_t x)   // "rep[0] - 1, but never 0" (zstd_decompress_block.pas:1150-1154) on a possibly symbolic value
+{
+    if (x & kSymbolicRep) return x + 1;
+    return x == 1 ? 1 : x - 1;
+}
+DEVI uint32_t rep_resolve(uint32_t x, const uint32_t* repIn)
+{
+    if (!(x & kSymbolicRep)) return x;
+    uint32_t const v = repIn[(x >> kRepIdxShift) & 3];
+    uint32_t const d = x & ((1u << kRepIdxShift) - 1);
+    return v > d ? v - d : 1;
+}
+
+__global__ __launch_bounds__(64) void k_sequences(BatchParams p)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t lds[kSeqJobs * kSeqJobWords];
+    uint32_t const lane = threadIdx.x;
+    uint32_t const sub = lane >> 4;
+    if (lane & 15) return;
+    uint32_t const job = blockIdx.x * kSeqJobs + sub;
+    if (job >= p.nSeqJobs) return;
+    uint32_t const b = p.seqJobs[job];
+    DevBlock const blk = p.blocks[b];
+    uint32_t* const tLL = lds + sub * kSeqJobWords;
+    uint32_t* const tML = tLL + 512;
+    uint32_t* const tOF = tML + 512;
+    int16_t* const norm = (int16_t*)(tOF + 256);
+    uint16_t* const symNext = (uint16_t*)(norm + 64);
+    DevBlockState* const st = p.state + b;
+
+    const uint8_t* const payload = p.src + blk.srcOff;
+    uint32_t off = blk.seqHdrOff;
+    uint32_t logs[3] = {0, 0, 0};
+    bool fail = false;
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+        uint32_t const type = t == T_LL ? blk.llType : t == T_OF ? blk.ofType : blk.mlType;
+        int32_t const srcB = t == T_LL ? blk.llSrc : t == T_OF ? blk.ofSrc : blk.mlSrc;
+        uint32_t* const cells = t == T_LL ? tLL : t == T_OF ? tOF : tML;
+        if (fail) break;
+        if (type != SET_REPEAT) {
+            if (off > blk.cSize) { fail = true; break; }
+            uint32_t const h = dev_build_from_desc(t, type, payload + off, blk.cSize - off, cells, norm, symNext, logs[t]);
+            if (h == kFail) { fail = true; break; }
+            off += h;
+        } else if (srcB == SRC_NONE) {
+            fail = true;
+        } else if (srcB == SRC_DICT) {
+            const uint32_t* const dc = t == T_LL ? p.dict->ll : t == T_OF ? p.dict->of : p.dict->ml;
+            uint32_t const lg = t == T_LL ? p.dict->llLog : t == T_OF ? p.dict->ofLog : p.dict->mlLog;
+            for (uint32_t u = 0; u < (1u << lg); u++) cells[u] = dc[u];
+            logs[t] = lg;
+        } else {
+            // rebuild from the block that defined the table: walk its descriptions up to table t
+            DevBlock const sb = p.blocks[srcB];
+            const uint8_t* const sp = p.src + sb.srcOff;
+            uint32_t o = sb.seqHdrOff;
+            for (int u = 0; u < t && !fail; u++) {
+                uint32_t const ut = u == T_LL ? sb.llType : sb.ofType;
+                uint32_t const sz = dev_desc_size(u, ut, sp, o, sb.cSize, norm);
+                if (sz == kFail) fail = true; else o += sz;
+            }
+            if (!fail) {
+                uint32_t const stype = t == T_LL ? sb.llType : t == T_OF ? sb.ofType : sb.mlType;
+                if (o > sb.cSize || dev_build_from_desc(t, stype, sp + o, sb.cSize - o, cells, norm, symNext, logs[t]) == kFail) fail = true;
+            }
+        }
+    }
+    BitR br;
+    if (!fail) {
+        if (off > blk.cSize || !br.init(payload + off, blk.cSize - off)) fail = true;
+    }
+    if (fail) {
+        st->seqErr = E_corruption; st->seqValid = 0; st->tailErr = 0; st->regen = blk.litSize;
+        st->repOut[0] = kSymbolicRep | (0u << kRepIdxShift); st->repOut[1] = kSymbolicRep | (1u << kRepIdxShift); st->repOut[2] = kSymbolicRep | (2u << kRepIdxShift);
+        return;
+    }
+
+    // ZSTD_initFseState x3, order LL, OF, ML (zstd_decompress_block.pas:1266-1268)
+    uint32_t sLL = br.read(logs[T_LL]); br.refill();
+    uint32_t sOF = br.read(logs[T_OF]); br.refill();
+    uint32_t sML = br.read(logs[T_ML]); br.refill();
+
+    uint32_t r0 = kSymbolicRep | (0u << kRepIdxShift), r1 = kSymbolicRep | (1u << kRepIdxShift), r2 = kSymbolicRep | (2u << kRepIdxShift);
+    uint64_t sumML = 0;
+    uint32_t* const out = p.seqBuf + blk.seqBufOff * 3;
+    uint32_t const nbSeq = blk.nbSeq;
+    uint32_t nValid = nbSeq;
+    for (uint32_t i = 0; i < nbSeq; i++) {
+        uint32_t const cLL = tLL[sLL], cOF = tOF[sOF], cML = tML[sML];
+        uint32_t const llCode = cLL >> 13, ofCode = cOF >> 13, mlCode = cML >> 13;
+        uint32_t const llBits = c_LL_bits[llCode], mlBits = c_ML_bits[mlCode];
+        uint32_t const llBase = c_LL_base[llCode], mlBase = c_ML_base[mlCode];
+        uint32_t offset;
+        if (ofCode > 1) {
+            uint32_t const raw = br.read(ofCode);
+            uint64_t const v = (uint64_t)((1ull << ofCode) - 3) + raw;
+            offset = v > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)v;   // anything this large is beyond every window: kept invalid
+            r2 = r1; r1 = r0; r0 = offset;
+        } else {
+            bool const ll0 = (llBase == 0);
+            if (ofCode == 0) {
+                if (!ll0) offset = r0;
+                else { offset = r1; r1 = r0; r0 = offset; }
+            } else {
+                uint32_t const code = 1 + (ll0 ? 1u : 0u) + br.read(1);
+                uint32_t const temp = code == 3 ? rep_dec1(r0) : (code == 1 ? r1 : r2);
+                if (code != 1) r2 = r1;
+                r1 = r0;
+                r0 = offset = temp;
+            }
+        }
+        uint32_t const ml = mlBase + br.read(mlBits);
+        if (llBits + mlBits + ofCode >= 31) br.refill();   // 64-bit refill rule (zstd_decompress_block.pas:1171-1174)
+        uint32_t const ll = llBase + br.read(llBits);
+        if (br.left() < 0) { nValid = i; break; }          // the extra bits of this sequence ran past the stream start
+        // state update, order LL, ML, OF (zstd_decompress_block.pas:1220-1225)
+        sLL = (cLL & 0x1FF) + br.read((cLL >> 9) & 15);
+        sML = (cML & 0x1FF) + br.read((cML >> 9) & 15);
+        sOF = (cOF & 0x1FF) + br.read((cOF >> 9) & 15);
+        out[3 * i] = ll; out[3 * i + 1] = ml; out[3 * i + 2] = offset;
+        sumML += ml;
+        if (i + 1 < nbSeq) br.refill();
+    }
+    st->seqErr = 0;
+    st->seqValid = nValid;
+    // after the last sequence the reader must be at (or, through the last state update, past) the stream start (:1301)
+    st->tailErr = (nValid == nbSeq && br.left() > 0) ? (uint32_t)E_corruption : 0u;
+    st->regen = (uint64_t)blk.litSize + sumML;
+    st->repOut[0] = r0; st->repOut[1] = r1; st->repOut[2] = r2;
+}
+
+// ---------------------------------------------------------------- stage 2: per-frame layout
+__global__ void k_layout(BatchParams p)
+{
+    uint32_t const fi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (fi >= p.nFrames) return;
+    DevFrame const f = p.frames[fi];
+    DevFrameStatus* const fs = p.status + fi;
+    fs->xxh64Low32 = 0; fs->regenSize = 0;
+    fs->errorCode = f.hostError;
+    if (f.hostError) return;
+    if (f.useDict && p.dict->status) { fs->errorCode = p.dict->status; return; }
+    uint32_t rep[3] = {1, 4, 8};   // repStartValue (zstd_internal.pas:13)
+    if (f.useDict && p.dict->hasEntropy) { rep[0] = p.dict->rep[0]; rep[1] = p.dict->rep[1]; rep[2] = p.dict->rep[2]; }
+    uint64_t pos = 0;
+    for (uint32_t b = f.firstBlock; b < f.firstBlock + f.nBlocks; b++) {
+        DevBlock const blk = p.blocks[b];
+        DevBlockState* const st = p.state + b;
+        st->dstOff = pos;
+        st->repIn[0] = rep[0]; st->repIn[1] = rep[1]; st->repIn[2] = rep[2];
+        uint64_t size;
+        if (blk.blockType == BT_STOP) break;
+        if (blk.blockType != BT_COMPRESSED) size = blk.origSize;
+        else if (blk.nbSeq == 0 || blk.hostLitErr || blk.hostSeqErr) size = blk.litSize;
+        else {
+            size = st->regen;
+            uint32_t const n0 = rep_resolve(st->repOut[0], rep), n1 = rep_resolve(st->repOut[1], rep), n2 = rep_resolve(st->repOut[2], rep);
+            rep[0] = n0; rep[1] = n1; rep[2] = n2;
+        }
+        st->regen = size;
+        pos += size;
+        if (pos > (1ull << 62)) pos = 1ull << 62;
+    }
+}
+
+// ---------------------------------------------------------------- stage 3: execute
+DEVI uint32_t wave_incl_scan(uint32_t v, uint32_t lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t const o = __shfl_up(v, d);
+        if (lane >= (uint32_t)d) v += o;
+    }
+    return v;
+}
+
+DEVI void coop_copy(uint8_t* dst, const uint8_t* src, uint64_t n, uint32_t lane)
+{
+    for (uint64_t i = lane; i < n; i += 64) dst[i] = src[i];
+}
+
+__global__ __launch_bounds__(64) void k_execute(BatchParams p)
+{
+    __shared__ uint32_t sStart[65], sLL[64], sOff[64], sLit[64];
+    uint32_t const lane = threadIdx.x;
+    uint32_t const fi = blockIdx.x;
+    DevFrame const f = p.frames[fi];
+    DevFrameStatus* const fs = p.status + fi;
+    if (fs->errorCode) return;   // host error or unusable dictionary (set by k_layout)
+    uint8_t* const fdst = p.dst + f.dstOff;
+    uint64_t const cap = f.dstCapacity;
+    uint32_t const dictN = f.useDict ? p.dictContentSize : 0;
+    const uint8_t* const dictEnd = p.dictContent + dictN;
+    uint32_t ferr = 0;
+    uint64_t produced = 0;
+
+    for (uint32_t b = f.firstBlock; b < f.firstBlock + f.nBlocks && !ferr; b++) {
+        DevBlock const blk = p.blocks[b];
+        DevBlockState const st = p.state[b];
+        uint64_t const bo = produced;           // block start inside the frame (== st.dstOff)
+        uint64_t const room = cap - bo;
+        if (blk.blockType == BT_STOP) { ferr = blk.hostLitErr; break; }
+        if (blk.blockType == BT_RAW) {
+            if (blk.origSize > room) { ferr = E_dstSize_tooSmall; break; }
+            coop_copy(fdst + bo, p.src + blk.srcOff, blk.origSize, lane);
+            produced += blk.origSize;
+            continue;
+        }
+        if (blk.blockType == BT_RLE) {
+            if (blk.origSize > room) { ferr = E_dstSize_tooSmall; break; }
+            uint8_t const v = p.src[blk.srcOff];
+            for (uint64_t i = lane; i < blk.origSize; i += 64) fdst[bo + i] = v;
+            produced += blk.origSize;
+            continue;
+        }
+        // compressed block: error precedence follows ZSTD_decompressBlock_internal (zstd_decompress_block.pas:1491-1542)
+        if (blk.hostLitErr) { ferr = blk.hostLitErr; break; }
+        bool const hufLits = blk.litType >= SET_COMPRESSED;
+        if (hufLits && st.litErr) { ferr = st.litErr; break; }
+        if (blk.hostSeqErr) { ferr = blk.hostSeqErr; break; }
+        if (blk.nbSeq && st.seqErr) { ferr = st.seqErr; break; }
+
+        const uint8_t* const litBase = hufLits ? p.litBuf + blk.litBufOff : p.src + blk.srcOff + blk.litHdrSize;
+        bool const litRle = (blk.litType == SET_RLE);
+        uint32_t const litSize = blk.litSize;
+        uint32_t const nValid = blk.nbSeq ? st.seqValid : 0;
+        const uint32_t* const seqs = p.seqBuf + blk.seqBufOff * 3;
+        uint64_t pos = 0;       // bytes of this block already produced
+        uint32_t litPos = 0;
+
+        for (uint32_t s0 = 0; s0 < nValid && !ferr; s0 += 64) {
+            uint32_t const n = nValid - s0 < 64 ? nValid - s0 : 64;
+            bool const have = lane < n;
+            uint32_t ll = 0, ml = 0, off = 1;
+            if (have) {
+                ll = seqs[3 * (s0 + lane)]; ml = seqs[3 * (s0 + lane) + 1]; off = seqs[3 * (s0 + lane) + 2];
+                off = rep_resolve(off, st.repIn);
+            }
+            uint32_t const len = ll + ml;                           // <= 2 * 131074
+            uint32_t const e = wave_incl_scan(len, lane);           // 64 * 262148 < 2^32
+            uint32_t const le = wave_incl_scan(ll, lane);
+            uint32_t const start = e - len;
+            uint64_t const lstart = (uint64_t)litPos + le - ll;
+            // per-sequence checks in the order of ZSTD_execSequenceEnd / ZSTD_execSequence (:896-1008)
+            uint32_t code = 0;
+            if (have) {
+                uint64_t const at = pos + start;                    // block-relative start of this sequence
+                if (at > room || len > room - at) code = E_dstSize_tooSmall;
+                else if (lstart > litSize || ll > litSize - lstart) code = E_corruption;
+                else if ((uint64_t)off > bo + at + ll + dictN) code = E_corruption;
+            }
+            unsigned long long const bad = __ballot(code != 0);
+            if (bad) { ferr = __shfl(code, __builtin_ctzll(bad)); break; }
+            wave_sync();      // earlier batches' stores are complete and visible; previous LDS reads done
+            sStart[lane] = start; sLL[lane] = ll; sOff[lane] = off; sLit[lane] = (uint32_t)lstart;
+            if (lane == 63) sStart[64] = e;
+            wave_sync();
+            uint32_t const total = __shfl(e, 63);
+            uint8_t* const bdst = fdst + bo + pos;
+            int64_t const batchAbs = (int64_t)(bo + pos);           // frame-relative position of batch byte 0
+            for (uint32_t k = lane; k < total; k += 64) {
+                uint32_t q = k;
+                uint8_t byte = 0;
+                for (int hop = 0; hop < 65; hop++) {
+                    // sequence owning batch byte q: last s with sStart[s] <= q
+                    uint32_t lo = 0, hi = n - 1;
+                    while (lo < hi) { uint32_t const mid = (lo + hi + 1) >> 1; if (sStart[mid] <= q) lo = mid; else hi = mid - 1; }
+                    uint32_t const r = q - sStart[lo];
+                    uint32_t const sll = sLL[lo];
+                    if (r < sll) { byte = litRle ? litBase[0] : litBase[sLit[lo] + r]; break; }
+                    uint32_t const m = r - sll, so = sOff[lo];
+                    int64_t const src = (int64_t)(sStart[lo] + sll) - (int64_t)so + (int64_t)(m < so ? m : m % so);
+                    if (src < 0) {
+                        int64_t const abs = batchAbs + src;
+                        byte = abs >= 0 ? fdst[abs] : dictEnd[abs];
+                        break;
+                    }
+                    q = (uint32_t)src;
+                }
+                bdst[k] = byte;
+            }
+            pos += total;
+            litPos += __shfl(le, 63);
+        }
+        if (ferr) break;
+        if (blk.nbSeq && nValid < blk.nbSeq) { ferr = E_corruption; break; }
+        if (blk.nbSeq && st.tailErr) { ferr = st.tailErr; break; }
+        {   // last literals (:1308-1317)
+            uint32_t const rest = litSize - litPos;
+            if (pos > room || rest > room - pos) { ferr = E_dstSize_tooSmall; break; }
+            uint8_t* const d = fdst + bo + pos;
+            if (litRle) { uint8_t const v = litBase[0]; for (uint32_t i = lane; i < rest; i += 64) d[i] = v; }
+            else coop_copy(d, litBase + litPos, rest, lane);
+            pos += rest;
+        }
+        produced += pos;
+    }
+    if (lane == 0) { fs->regenSize = produced; fs->errorCode = ferr; }
+}
+
+// ---------------------------------------------------------------- stage 4: XXH64 + verdict
+constexpr uint64_t P1 = 0x9E3779B185EBCA87ULL, P2 = 0xC2B2AE3D27D4EB4FULL, P3 = 0x165667B19E3779F9ULL,
+                   P4 = 0x85EBCA77C2B2AE63ULL, P5 = 0x27D4EB2F165667C5ULL;
+DEVI uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+DEVI uint64_t xxh_round(uint64_t acc, uint64_t in) { acc += in * P2; acc = rotl64(acc, 31); return acc * P1; }
+DEVI uint64_t xxh_merge(uint64_t acc, uint64_t v) { v = xxh_round(0, v); acc ^= v; return acc * P1 + P4; }
+
+// XXH64 of [p, p+len) with seed 0, computed by a group of 4 consecutive lanes (one accumulator each);
+// the result is valid on the group's first lane (xxhash.pas:409-488).
+DEVI uint64_t xxh64_group4(const uint8_t* p, uint64_t len, uint32_t gl, uint32_t lead)
+{
+    uint64_t h;
+    uint64_t const stripes = len / 32;
+    uint64_t v = gl == 0 ? P1 + P2 : gl == 1 ? P2 : gl == 2 ? 0 : 0 - P1;
+    const uint8_t* q = p + 8 * gl;
+    for (uint64_t s = 0; s < stripes; s++, q += 32) v = xxh_round(v, ld_u64(q));
+    uint64_t const v1 = __shfl(v, lead), v2 = __shfl(v, lead + 1), v3 = __shfl(v, lead + 2), v4 = __shfl(v, lead + 3);
+    if (len >= 32) {
+        h = rotl64(v1, 1) + rotl64(v2, 7) + rotl64(v3, 12) + rotl64(v4, 18);
+        h = xxh_merge(h, v1); h = xxh_merge(h, v2); h = xxh_merge(h, v3); h = xxh_merge(h, v4);
+    } else h = P5;
+    h += len;
+    const uint8_t* t = p + stripes * 32;
+    const uint8_t* const end = p + len;
+    if (gl == 0) {
+        while (t + 8 <= end) { h ^= xxh_round(0, ld_u64(t)); h = rotl64(h, 27) * P1 + P4; t += 8; }
+        if (t + 4 <= end) { uint32_t w; __builtin_memcpy(&w, t, 4); h ^= (uint64_t)w * P1; h = rotl64(h, 23) * P2 + P3; t += 4; }
+        while (t < end) { h ^= (uint64_t)(*t) * P5; h = rotl64(h, 11) * P1; t++; }
+        h ^= h >> 33; h *= P2; h ^= h >> 29; h *= P3; h ^= h >> 32;
+    }
+    return h;
+}
+
+__global__ __launch_bounds__(64) void k_checksum(BatchParams p)
+{
+    uint32_t const lane = threadIdx.x;
+    uint32_t const gl = lane & 3, lead = lane & ~3u;
+    uint32_t const fi = blockIdx.x * 16 + (lane >> 2);
+    if (fi >= p.nFrames) return;
+    DevFrame const f = p.frames[fi];
+    DevFrameStatus* const fs = p.status + fi;
+    uint32_t err = fs->errorCode;
+    uint64_t const regen = fs->regenSize;
+    // frame verdict (zstd_decompressf.pas:810-828): content size, then checksum
+    if (!err && f.contentSize != ~0ull && regen != f.contentSize) err = E_corruption;
+    bool const doSum = !err && f.checksumFlag != 0;
+    uint64_t h = 0;
+    if (doSum && f.checksumFlag == 1) h = xxh64_group4(p.dst + f.dstOff, regen, gl, lead);
+    if (gl == 0) {
+        if (doSum) {
+            if (f.checksumFlag == 2) err = E_checksum_wrong;          // trailer missing from the source
+            else { fs->xxh64Low32 = (uint32_t)h; if ((uint32_t)h != f.checksum) err = E_checksum_wrong; }
+        }
+        fs->errorCode = err;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_xxh64(const uint8_t* base, const uint64_t* off, const uint64_t* len, uint32_t n, uint64_t* out)
+{
+    uint32_t const lane = threadIdx.x;
+    uint32_t const gl = lane & 3, lead = lane & ~3u;
+    uint32_t const i = blockIdx.x * 16 + (lane >> 2);
+    if (i >= n) return;
+    uint64_t const h = xxh64_group4(base + off[i], len[i], gl, lead);
+    if (gl == 0) out[i] = h;
+}
+
+// ---------------------------------------------------------------- dictionary digest (single lane)
+__global__ __launch_bounds__(64) void k_digest_dict(const uint8_t* dict, uint32_t dictSize, DevDict* out)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t scratch[2048];
+    __shared__ uint8_t weights[256];
+    __shared__ uint16_t pos[256];
+    __shared__ uint32_t rank[16];
+    __shared__ int16_t norm[64];
+    __shared__ uint16_t symNext[64];
+    if (threadIdx.x != 0) return;
+    out->status = E_dictionary_corrupted;
+    out->hasEntropy = 1;
+    if (dictSize <= 8) return;
+    uint32_t o = 8;
+    {   // Huffman table for literals; the reference builds the double-symbol form here (:1288), which decodes the same bytes
+        uint32_t nbSymbols = 0, tableLog = 0;
+        uint32_t const h = dev_huf_read_table_desc(dict + o, dictSize - o, weights, pos, rank, scratch, nbSymbols, tableLog);
+        if (h == kFail) return;
+        for (uint32_t n = 0; n < nbSymbols; n++) {
+            uint32_t const w = weights[n];
+            if (!w) continue;
+            uint32_t const len = (1u << w) >> 1;
+            uint16_t const cell = (uint16_t)(n | ((tableLog + 1 - w) << 8));
+            for (uint32_t u = 0; u < len; u++) out->huf[pos[n] + u] = cell;
+        }
+        out->hufLog = tableLog;
+        o += h;
+    }
+    // OF, ML, LL in that order (:1294-1340)
+    for (int k = 0; k < 3; k++) {
+        int const t = k == 0 ? T_OF : k == 1 ? T_ML : T_LL;
+        uint32_t* const cells = t == T_LL ? out->ll : t == T_OF ? out->of : out->ml;
+        uint32_t maxSV = tbl_max(t), tableLog = 0;
+        if (o > dictSize) return;
+        uint32_t const h = dev_readNCount(norm, maxSV, tableLog, dict + o, dictSize - o);
+        if (h == kFail || tableLog > tbl_maxLog(t)) return;
+        dev_build_seq_table(cells, norm, symNext, maxSV, tableLog);
+        if (t == T_LL) out->llLog = tableLog; else if (t == T_OF) out->ofLog = tableLog; else out->mlLog = tableLog;
+        o += h;
+    }
+    if (o + 12 > dictSize) return;
+    uint32_t const contentSize = dictSize - (o + 12);
+    for (int i = 0; i < 3; i++) {
+        uint32_t const rep = rd32z(dict, dictSize, o); o += 4;
+        if (rep == 0 || rep > contentSize) return;
+        out->rep[i] = rep;
+    }
+    out->entropySize = o;
+    out->status = 0;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------- launchers
+void launch_literals(const BatchParams& p, void* stream)
+{
+    if (!p.nLitJobs) return;
+    hipLaunchKernelGGL(k_literals, dim3((p.nLitJobs + kHufJobs - 1) / kHufJobs), dim3(64), 0, (hipStream_t)stream, p);
+}
+void launch_sequences(const BatchParams& p, void* stream)
+{
+    if (!p.nSeqJobs) return;
+    hipLaunchKernelGGL(k_sequences, dim3((p.nSeqJobs + kSeqJobs - 1) / kSeqJobs), dim3(64), 0, (hipStream_t)stream, p);
+}
+void launch_layout(const BatchParams& p, void* stream)
+{
+    if (!p.nFrames) return;
+    hipLaunchKernelGGL(k_layout, dim3((p.nFrames + 63) / 64), dim3(64), 0, (hipStream_t)stream, p);
+}
+void launch_execute(const BatchParams& p, void* stream)
+{
+    if (!p.nFrames) return;
+    hipLaunchKernelGGL(k_execute, dim3(p.nFrames), dim3(64), 0, (hipStream_t)stream, p);
+}
+void launch_checksum(const BatchParams& p, void* stream)
+{
+    if (!p.nFrames) return;
+    hipLaunchKernelGGL(k_checksum, dim3((p.nFrames + 15) / 16), dim3(64), 0, (hipStream_t)stream, p);
+}
+void launch_digest_dict(const uint8_t* devDict, uint32_t dictSize, DevDict* out, void* stream)
+{
+    hipLaunchKernelGGL(k_digest_dict, dim3(1), dim3(64), 0, (hipStream_t)stream, devDict, dictSize, out);
+}
+void launch_xxh64(const uint8_t* base, const uint64_t* off, const uint64_t* len, uint32_t n, uint64_t* out, void* stream)
+{
+    if (!n) return;
+    hipLaunchKernelGGL(k_xxh64, dim3((n + 15) / 16), dim3(64), 0, (hipStream_t)stream, base, off, len, n, out);
+}
+
+}  // namespace zg

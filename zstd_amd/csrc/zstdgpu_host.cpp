@@ -1,0 +1,779 @@
+// Host side of the C ABI declared in include/zstdgpu.h: frame/block header walk (the part of
+// decompress/zstd_decompressf.pas that stays on the host), section-header parse, table linking,
+// dictionary upload, batch management, and the one-shot drop-ins.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/zstdgpu.h"
+#include "zstdgpu_internal.h"
+
+using namespace zg;
+
+namespace {
+
+inline size_t mkerr(uint32_t code) { return (size_t)0 - (size_t)code; }
+inline bool iserr(size_t v) { return v > (size_t)0 - (size_t)E_maxCode; }
+
+inline uint32_t rd16(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
+inline uint32_t rd24(const uint8_t* p) { return rd16(p) | ((uint32_t)p[2] << 16); }
+inline uint32_t rd32(const uint8_t* p) { return rd24(p) | ((uint32_t)p[3] << 24); }
+inline uint64_t rd64(const uint8_t* p) { return (uint64_t)rd32(p) | ((uint64_t)rd32(p + 4) << 32); }
+
+constexpr uint32_t kMagic = 0xFD2FB528u;           // zstd.pas:5
+constexpr uint32_t kMagicDict = 0xEC30A437u;       // zstd.pas:6
+constexpr uint32_t kMagicSkipStart = 0x184D2A50u;  // zstd.pas:7-8
+constexpr uint32_t kMagicSkipMask = 0xFFFFFFF0u;
+constexpr uint32_t kWindowLogMax = 31;
+constexpr uint32_t kLongNbSeq = 0x7F00;
+
+struct FrameHeader {
+    uint64_t contentSize = ZSTDGPU_CONTENTSIZE_UNKNOWN, windowSize = 0;
+    uint32_t dictID = 0, checksumFlag = 0, headerSize = 0;
+};
+
+// ZSTD_frameHeaderSize_internal (zstd_decompressf.pas:246-279); srcSize >= 5 required
+size_t frame_header_size(const uint8_t* src, size_t srcSize)
+{
+    static const size_t fcs[4] = {0, 2, 4, 8}, did[4] = {0, 1, 2, 4};
+    if (srcSize < 5) return mkerr(E_srcSize_wrong);
+    uint8_t const fhd = src[4];
+    uint32_t const singleSegment = (fhd >> 5) & 1, fcsId = fhd >> 6;
+    return 5 + !singleSegment + did[fhd & 3] + fcs[fcsId] + (singleSegment && !fcsId);
+}
+
+// ZSTD_getFrameHeader_advanced (zstd_decompressf.pas:281-395): 0 ok, >0 bytes wanted, or error
+size_t get_frame_header(FrameHeader& h, const uint8_t* src, size_t srcSize)
+{
+    if (srcSize < 5) return 5;
+    if (rd32(src) != kMagic) return mkerr(E_prefix_unknown);
+    size_t const fhsize = frame_header_size(src, srcSize);
+    if (srcSize < fhsize) return fhsize;
+    h.headerSize = (uint32_t)fhsize;
+    uint8_t const fhd = src[4];
+    size_t pos = 5;
+    uint32_t const dictIDSizeCode = fhd & 3, singleSegment = (fhd >> 5) & 1, fcsID = fhd >> 6;
+    h.checksumFlag = (fhd >> 2) & 1;
+    if (fhd & 0x08) return mkerr(E_frameParameter_unsupported);
+    if (!singleSegment) {
+        uint8_t const wl = src[pos++];
+        uint32_t const windowLog = (wl >> 3) + 10;
+        if (windowLog > kWindowLogMax) return mkerr(E_frameParameter_windowTooLarge);
+        h.windowSize = 1ULL << windowLog;
+        h.windowSize += (h.windowSize >> 3) * (wl & 7);
+    }
+    switch (dictIDSizeCode) {
+        case 1: h.dictID = src[pos]; pos += 1; break;
+        case 2: h.dictID = rd16(src + pos); pos += 2; break;
+        case 3: h.dictID = rd32(src + pos); pos += 4; break;
+        default: break;
+    }
+    switch (fcsID) {
+        case 0: if (singleSegment) h.contentSize = src[pos]; break;
+        case 1: h.contentSize = rd16(src + pos) + 256; break;
+        case 2: h.contentSize = rd32(src + pos); break;
+        case 3: h.contentSize = rd64(src + pos); break;
+    }
+    if (singleSegment) h.windowSize = h.contentSize;
+    return 0;
+}
+
+// readSkippableFrameSize (zstd_decompressf.pas:441-459)
+size_t skippable_size(const uint8_t* src, size_t srcSize)
+{
+    if (srcSize < 8) return mkerr(E_srcSize_wrong);
+    uint32_t const sz = rd32(src + 4);
+    if ((uint32_t)(sz + 8) < sz) return mkerr(E_frameParameter_unsupported);
+    size_t const total = (size_t)8 + sz;
+    if (total > srcSize) return mkerr(E_srcSize_wrong);
+    return total;
+}
+
+// Walk one frame: header, then every block header (ZSTD_decompressFrame :734-808 without the decoding,
+// i.e. the loop of ZSTD_findFrameSizeInfo :566-639).  Appends block descriptors; returns bytes consumed.
+size_t walk_frame(const uint8_t* base, const zstdgpu_frame_in& in, uint32_t frameIdx, uint32_t batchDictID,
+                  zstdgpu_frame_desc& fd, std::vector<zstdgpu_block_desc>* blocks, size_t& nBlocksOut)
+{
+    const uint8_t* const src = base + in.srcOff;
+    size_t remaining = in.srcSize;
+    fd = zstdgpu_frame_desc{};
+    fd.srcOff = in.srcOff; fd.srcSize = in.srcSize; fd.dstOff = in.dstOff; fd.dstCapacity = in.dstCapacity;
+    fd.contentSize = ZSTDGPU_CONTENTSIZE_UNKNOWN;
+    fd.firstBlock = (uint32_t)nBlocksOut;
+    auto fail = [&](uint32_t code) { fd.hostError = code; fd.nBlocks = 0; nBlocksOut = fd.firstBlock; if (blocks) blocks->resize(fd.firstBlock); return (size_t)0; };
+    if (remaining < 6 + 3) return fail(E_srcSize_wrong);
+    size_t const fhsize = frame_header_size(src, 5);
+    if (remaining < fhsize + 3) return fail(E_srcSize_wrong);
+    FrameHeader fh;
+    size_t const r = get_frame_header(fh, src, fhsize);
+    if (iserr(r)) return fail((uint32_t)(0 - r));
+    if (r > 0) return fail(E_srcSize_wrong);
+    if (fh.dictID && fh.dictID != batchDictID) return fail(E_dictionary_wrong);   // ZSTD_decodeFrameHeader :541-563
+    fd.contentSize = fh.contentSize; fd.windowSize = fh.windowSize; fd.dictID = fh.dictID;
+    size_t ip = fhsize;
+    remaining -= fhsize;
+    for (;;) {
+        zstdgpu_block_desc bd{};
+        bd.frameIdx = frameIdx;
+        auto stop = [&](uint32_t code) { bd.blockType = BT_STOP; bd.hostError = (uint16_t)code; bd.lastBlock = 1; };
+        bool done = false;
+        if (remaining < 3) { stop(E_srcSize_wrong); done = true; }   // ZSTD_getcBlockSize (zstd_decompress_block.pas:190-207)
+        else {
+            uint32_t const hdr = rd24(src + ip);
+            uint32_t const type = (hdr >> 1) & 3, size = hdr >> 3;
+            uint32_t const cSize = type == BT_RLE ? 1 : size;
+            if (type == 3) { stop(E_corruption); done = true; }
+            else if (cSize > remaining - 3) { stop(E_srcSize_wrong); done = true; }
+            else {
+                bd.srcOff = in.srcOff + ip + 3;
+                bd.cSize = cSize; bd.origSize = size; bd.blockType = (uint8_t)type; bd.lastBlock = hdr & 1;
+                ip += 3 + cSize; remaining -= 3 + cSize;
+                done = bd.lastBlock;
+            }
+        }
+        if (blocks) blocks->push_back(bd);
+        nBlocksOut++;
+        if (done) { if (bd.blockType == BT_STOP) { fd.nBlocks = (uint32_t)nBlocksOut - fd.firstBlock; return ip; } break; }
+    }
+    fd.nBlocks = (uint32_t)nBlocksOut - fd.firstBlock;
+    if (fh.checksumFlag) {
+        if (remaining < 4) fd.checksumFlag = 2;   // trailer missing: checksum_wrong once everything else passed (:817)
+        else { fd.checksumFlag = 1; fd.checksum = rd32(src + ip); ip += 4; remaining -= 4; }
+    }
+    return ip;
+}
+
+}  // namespace
+
+// ===================================================================== objects
+struct zstdgpu_ctx {
+    int device = 0;
+    // grow-only device staging for the host-buffer drop-ins
+    uint8_t *dSrc = nullptr, *dDst = nullptr;
+    size_t dSrcCap = 0, dDstCap = 0;
+};
+
+struct zstdgpu_ddict {
+    zstdgpu_ctx* ctx = nullptr;
+    uint8_t* dBytes = nullptr;     // whole dictionary on the device
+    DevDict* dDict = nullptr;
+    uint32_t size = 0, dictID = 0, hasEntropy = 0, entropySize = 0, status = 0;
+};
+
+struct zstdgpu_batch {
+    zstdgpu_ctx* ctx = nullptr;
+    const zstdgpu_ddict* ddict = nullptr;
+    std::vector<DevBlock> hBlocks;
+    std::vector<DevFrame> hFrames;
+    std::vector<uint32_t> hLitJobs, hSeqJobs;
+    DevBlock* dBlocks = nullptr; DevBlockState* dState = nullptr; DevFrame* dFrames = nullptr; DevFrameStatus* dStatus = nullptr;
+    uint8_t* dLitBuf = nullptr; uint32_t* dSeqBuf = nullptr; uint32_t *dLitJobs = nullptr, *dSeqJobs = nullptr;
+    uint64_t litBytes = 0, nSeqTotal = 0, srcBytes = 0, scratchBytes = 0;
+    bool profiling = false;
+    hipEvent_t ev[ZSTDGPU_NUM_STAGES + 1] = {};
+    bool evReady = false, evRecorded = false;
+    hipStream_t lastStream = nullptr;
+};
+
+namespace {
+
+bool set_device(const zstdgpu_ctx* ctx) { return hipSetDevice(ctx->device) == hipSuccess; }
+
+template <typename T>
+bool dalloc(T*& p, size_t n, uint64_t& acct)
+{
+    size_t const bytes = (n ? n : 1) * sizeof(T);
+    if (hipMalloc((void**)&p, bytes) != hipSuccess) { p = nullptr; return false; }
+    acct += bytes;
+    return true;
+}
+
+// Literals-section header (switch of ZSTD_decodeLiteralsBlock, zstd_decompress_block.pas:243-274, :333-400)
+// and the count/modes bytes of ZSTD_decodeSeqHeaders (:708-742).
+void parse_sections(const uint8_t* payload, DevBlock& d)
+{
+    uint32_t const cSize = d.cSize;
+    if (cSize >= kBlockSizeMax) { d.hostLitErr = E_srcSize_wrong; return; }       // :1513
+    if (cSize < 3) { d.hostLitErr = E_corruption; return; }                        // MIN_CBLOCK_SIZE
+    uint32_t const type = payload[0] & 3, lhl = (payload[0] >> 2) & 3;
+    d.litType = (uint8_t)type;
+    uint32_t section = 0;
+    if (type >= SET_COMPRESSED) {
+        if (type == SET_REPEAT && d.hufSrc == SRC_NONE) { d.hostLitErr = E_dictionary_corrupted; return; }   // :233-234
+        if (cSize < 5) { d.hostLitErr = E_corruption; return; }
+        uint32_t const lhc = rd32(payload);
+        uint32_t lhSize, litSize, litCSize;
+        switch (lhl) {
+            case 0: case 1: default: d.singleStream = !lhl; lhSize = 3; litSize = (lhc >> 4) & 0x3FF; litCSize = (lhc >> 14) & 0x3FF; break;
+            case 2: lhSize = 4; litSize = (lhc >> 4) & 0x3FFF; litCSize = lhc >> 18; break;
+            case 3: lhSize = 5; litSize = (lhc >> 4) & 0x3FFFF; litCSize = (lhc >> 22) + ((uint32_t)payload[4] << 10); break;
+        }
+        if (litSize > kBlockSizeMax) { d.hostLitErr = E_corruption; return; }
+        if (litCSize + lhSize > cSize) { d.hostLitErr = E_corruption; return; }
+        d.litHdrSize = (uint8_t)lhSize; d.litSize = litSize; d.litCSize = litCSize;
+        section = lhSize + litCSize;
+    } else {
+        uint32_t lhSize, litSize;
+        switch (lhl) {
+            case 0: case 2: default: lhSize = 1; litSize = payload[0] >> 3; break;
+            case 1: lhSize = 2; litSize = rd16(payload) >> 4; break;
+            case 3: lhSize = 3; litSize = rd24(payload) >> 4;
+                    if (type == SET_RLE && cSize < 4) { d.hostLitErr = E_corruption; return; }
+                    break;
+        }
+        d.litHdrSize = (uint8_t)lhSize; d.litSize = litSize;
+        if (type == SET_BASIC) {
+            if (litSize + lhSize > cSize) { d.hostLitErr = E_corruption; return; }
+            d.litCSize = litSize; section = lhSize + litSize;
+        } else {
+            if (litSize > kBlockSizeMax) { d.hostLitErr = E_corruption; return; }
+            d.litCSize = 1; section = lhSize + 1;
+        }
+    }
+    // sequences header
+    uint32_t const rem = cSize - section;
+    const uint8_t* ip = payload + section;
+    const uint8_t* const iend = payload + cSize;
+    if (rem < 1) { d.hostSeqErr = E_srcSize_wrong; return; }
+    uint32_t nbSeq = *ip++;
+    if (!nbSeq) { if (rem != 1) d.hostSeqErr = E_srcSize_wrong; d.nbSeq = 0; return; }
+    if (nbSeq > 0x7F) {
+        if (nbSeq == 0xFF) { if (ip + 2 > iend) { d.hostSeqErr = E_srcSize_wrong; return; } nbSeq = rd16(ip) + kLongNbSeq; ip += 2; }
+        else { if (ip >= iend) { d.hostSeqErr = E_srcSize_wrong; return; } nbSeq = ((nbSeq - 0x80) << 8) + *ip++; }
+    }
+    d.nbSeq = nbSeq;
+    if (ip + 1 > iend) { d.hostSeqErr = E_srcSize_wrong; d.nbSeq = 0; return; }
+    d.llType = *ip >> 6; d.ofType = (*ip >> 4) & 3; d.mlType = (*ip >> 2) & 3;
+    ip++;
+    d.seqHdrOff = (uint32_t)(ip - payload);
+}
+
+void free_batch_device(zstdgpu_batch* b)
+{
+    hipFree(b->dBlocks); hipFree(b->dState); hipFree(b->dFrames); hipFree(b->dStatus);
+    hipFree(b->dLitBuf); hipFree(b->dSeqBuf); hipFree(b->dLitJobs); hipFree(b->dSeqJobs);
+    if (b->evReady) for (auto& e : b->ev) hipEventDestroy(e);
+}
+
+}  // namespace
+
+// ===================================================================== error helpers
+extern "C" unsigned zstdgpu_isError(size_t code) { return iserr(code); }
+extern "C" unsigned zstdgpu_getErrorCode(size_t code) { return iserr(code) ? (unsigned)((size_t)0 - code) : 0; }
+extern "C" unsigned zstdgpu_versionNumber(void) { return ZSTDGPU_VERSION_NUMBER; }
+extern "C" const char* zstdgpu_getErrorName(size_t code)
+{
+    switch (zstdgpu_getErrorCode(code)) {   // strings of ERR_getErrorString (error_private.pas:70-106)
+        case 0: return "No error detected";
+        case 1: return "Error (generic)";
+        case 10: return "Unknown frame descriptor";
+        case 12: return "Version not supported";
+        case 14: return "Unsupported frame parameter";
+        case 16: return "Frame requires too much memory for decoding";
+        case 20: return "Corrupted block detected";
+        case 22: return "Restored data doesn't match checksum";
+        case 30: return "Dictionary is corrupted";
+        case 32: return "Dictionary mismatch";
+        case 64: return "Allocation error : not enough memory";
+        case 70: return "Destination buffer is too small";
+        case 72: return "Src size is incorrect";
+        default: return "Unspecified error code";
+    }
+}
+
+// ===================================================================== context
+extern "C" zstdgpu_ctx* zstdgpu_create(int device)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return nullptr;
+    if (hipSetDevice(device) != hipSuccess) return nullptr;
+    zstdgpu_ctx* c = new (std::nothrow) zstdgpu_ctx;
+    if (c) c->device = device;
+    return c;
+}
+extern "C" void zstdgpu_destroy(zstdgpu_ctx* ctx)
+{
+    if (!ctx) return;
+    set_device(ctx);
+    hipFree(ctx->dSrc); hipFree(ctx->dDst);
+    delete ctx;
+}
+
+// ===================================================================== header queries
+extern "C" unsigned long long zstdgpu_getFrameContentSize(const void* src, size_t srcSize)
+{
+    const uint8_t* s = (const uint8_t*)src;
+    if (srcSize >= 4 && (rd32(s) & kMagicSkipMask) == kMagicSkipStart) return 0;   // :374-385 (skippable: content size 0)
+    FrameHeader h;
+    if (get_frame_header(h, s, srcSize) != 0) return ZSTDGPU_CONTENTSIZE_ERROR;
+    return h.contentSize;
+}
+extern "C" size_t zstdgpu_findFrameCompressedSize(const void* srcv, size_t srcSize)
+{
+    const uint8_t* src = (const uint8_t*)srcv;
+    if (srcSize >= 8 && (rd32(src) & kMagicSkipMask) == kMagicSkipStart) return skippable_size(src, srcSize);
+    FrameHeader h;
+    size_t const r = get_frame_header(h, src, srcSize);
+    if (iserr(r)) return r;
+    if (r > 0) return mkerr(E_srcSize_wrong);
+    size_t ip = h.headerSize, remaining = srcSize - h.headerSize;
+    for (;;) {
+        if (remaining < 3) return mkerr(E_srcSize_wrong);
+        uint32_t const hdr = rd24(src + ip);
+        uint32_t const type = (hdr >> 1) & 3;
+        if (type == 3) return mkerr(E_corruption);
+        size_t const cSize = type == BT_RLE ? 1 : (hdr >> 3);
+        if (3 + cSize > remaining) return mkerr(E_srcSize_wrong);
+        ip += 3 + cSize; remaining -= 3 + cSize;
+        if (hdr & 1) break;
+    }
+    if (h.checksumFlag) { if (remaining < 4) return mkerr(E_srcSize_wrong); ip += 4; }
+    return ip;
+}
+extern "C" unsigned zstdgpu_getDictID_fromDict(const void* dict, size_t dictSize)
+{
+    if (dictSize < 8 || rd32((const uint8_t*)dict) != kMagicDict) return 0;
+    return rd32((const uint8_t*)dict + 4);
+}
+extern "C" unsigned zstdgpu_getDictID_fromFrame(const void* src, size_t srcSize)
+{
+    FrameHeader h;
+    if (get_frame_header(h, (const uint8_t*)src, srcSize) != 0) return 0;
+    return h.dictID;
+}
+
+// ===================================================================== dictionaries
+extern "C" zstdgpu_ddict* zstdgpu_createDDict(zstdgpu_ctx* ctx, const void* dict, size_t dictSize)
+{
+    if (!ctx || !set_device(ctx) || dictSize > 0x7FFFFFFFu) return nullptr;
+    zstdgpu_ddict* d = new (std::nothrow) zstdgpu_ddict;
+    if (!d) return nullptr;
+    d->ctx = ctx; d->size = (uint32_t)dictSize;
+    uint64_t acct = 0;
+    if (!dalloc(d->dBytes, dictSize + 16, acct) || !dalloc(d->dDict, 1, acct)) { zstdgpu_freeDDict(d); return nullptr; }
+    if (dictSize && hipMemcpy(d->dBytes, dict, dictSize, hipMemcpyHostToDevice) != hipSuccess) { zstdgpu_freeDDict(d); return nullptr; }
+    // ZSTD_decompress_insertDictionary (zstd_decompressf.pas:1358-1384): magic -> entropy tables + content, else raw content
+    if (dictSize >= 8 && rd32((const uint8_t*)dict) == kMagicDict) {
+        d->hasEntropy = 1;
+        d->dictID = rd32((const uint8_t*)dict + 4);
+        launch_digest_dict(d->dBytes, d->size, d->dDict, nullptr);
+        uint32_t head[3] = {0, 0, 0};   // status, hasEntropy, entropySize
+        if (hipMemcpy(head, d->dDict, sizeof(head), hipMemcpyDeviceToHost) != hipSuccess) { zstdgpu_freeDDict(d); return nullptr; }
+        d->status = head[0]; d->entropySize = head[2];
+    } else {
+        DevDict* h = new (std::nothrow) DevDict;
+        if (!h) { zstdgpu_freeDDict(d); return nullptr; }
+        memset(h, 0, sizeof(*h));
+        hipError_t const e = hipMemcpy(d->dDict, h, sizeof(*h), hipMemcpyHostToDevice);
+        delete h;
+        if (e != hipSuccess) { zstdgpu_freeDDict(d); return nullptr; }
+    }
+    return d;
+}
+extern "C" void zstdgpu_freeDDict(zstdgpu_ddict* d)
+{
+    if (!d) return;
+    set_device(d->ctx);
+    hipFree(d->dBytes); hipFree(d->dDict);
+    delete d;
+}
+
+// ===================================================================== descriptor builder
+extern "C" size_t zstdgpu_buildDescriptors(const void* hostSrc, size_t srcBytes, const zstdgpu_frame_in* in, uint32_t nFrames,
+                                           zstdgpu_frame_desc* frames, zstdgpu_block_desc* blocks, size_t blockCapacity)
+{
+    // dictID checks need the batch dictionary: done again in zstdgpu_batch_create; here any dictID is accepted
+    std::vector<zstdgpu_block_desc> tmp;
+    size_t nBlocks = 0;
+    for (uint32_t i = 0; i < nFrames; i++) {
+        zstdgpu_frame_desc fd;
+        if (in[i].srcOff > srcBytes || in[i].srcSize > srcBytes - in[i].srcOff) {
+            fd = zstdgpu_frame_desc{}; fd.srcOff = in[i].srcOff; fd.srcSize = in[i].srcSize; fd.dstOff = in[i].dstOff; fd.dstCapacity = in[i].dstCapacity;
+            fd.firstBlock = (uint32_t)nBlocks; fd.hostError = E_srcSize_wrong; fd.contentSize = ZSTDGPU_CONTENTSIZE_UNKNOWN;
+        } else {
+            // peek the dictID so the walk does not reject it; the batch compares it with its dictionary
+            FrameHeader fh;
+            uint32_t did = 0;
+            if (get_frame_header(fh, (const uint8_t*)hostSrc + in[i].srcOff, in[i].srcSize) == 0) did = fh.dictID;
+            size_t const used = walk_frame((const uint8_t*)hostSrc, in[i], i, did, fd, &tmp, nBlocks);
+            if (!fd.hostError && used != in[i].srcSize && fd.checksumFlag != 2 && !(fd.nBlocks && tmp.back().blockType == BT_STOP))
+                { fd.hostError = E_srcSize_wrong; }   // bytes after the frame: one entry is exactly one frame
+        }
+        if (frames) frames[i] = fd;
+    }
+    if (blocks) {
+        if (nBlocks > blockCapacity) return mkerr(E_dstSize_tooSmall);
+        if (nBlocks) memcpy(blocks, tmp.data(), nBlocks * sizeof(zstdgpu_block_desc));
+    }
+    return nBlocks;
+}
+
+// ===================================================================== batch
+extern "C" zstdgpu_batch* zstdgpu_batch_create(zstdgpu_ctx* ctx, const void* hostSrc, size_t srcBytes,
+                                               const zstdgpu_frame_desc* frames, uint32_t nFrames,
+                                               const zstdgpu_block_desc* blocks, uint32_t nBlocks, const zstdgpu_ddict* ddict)
+{
+    if (!ctx || !set_device(ctx)) return nullptr;
+    zstdgpu_batch* B = new (std::nothrow) zstdgpu_batch;
+    if (!B) return nullptr;
+    B->ctx = ctx; B->ddict = ddict;
+    const uint8_t* const src = (const uint8_t*)hostSrc;
+    bool const dictEntropy = ddict && ddict->hasEntropy;
+    uint32_t const batchDictID = ddict ? ddict->dictID : 0;
+    B->hBlocks.resize(nBlocks);
+    B->hFrames.resize(nFrames);
+    uint64_t litOff = 0, seqOff = 0;
+    for (uint32_t fi = 0; fi < nFrames; fi++) {
+        const zstdgpu_frame_desc& fd = frames[fi];
+        DevFrame& f = B->hFrames[fi];
+        f.dstOff = fd.dstOff; f.dstCapacity = fd.dstCapacity; f.contentSize = fd.contentSize;
+        f.firstBlock = fd.firstBlock; f.nBlocks = fd.nBlocks;
+        f.checksumFlag = fd.checksumFlag; f.checksum = fd.checksum;
+        f.hostError = fd.hostError;
+        f.useDict = ddict ? 1 : 0;
+        if (!f.hostError && fd.dictID && fd.dictID != batchDictID) f.hostError = E_dictionary_wrong;
+        if (!f.hostError && (uint64_t)fd.firstBlock + fd.nBlocks > nBlocks) f.hostError = E_generic;
+        if (!f.hostError && fd.dstCapacity > 0x7FFFFFFFull) f.dstCapacity = 0x7FFFFFFFull;   // frames regenerate < 2 GiB (the port's sizes are int32)
+        if (f.hostError) { f.nBlocks = 0; continue; }
+        B->srcBytes += fd.srcSize;
+        // entropy state carried from block to block inside the frame (zstd_ddict.pas:109-126): which block defines each table
+        int32_t hufDef = dictEntropy ? SRC_DICT : SRC_NONE;
+        int32_t llDef = hufDef, ofDef = hufDef, mlDef = hufDef;
+        bool dead = false;   // a host-detected error ends the frame: later blocks are never reached
+        for (uint32_t b = fd.firstBlock; b < fd.firstBlock + fd.nBlocks; b++) {
+            const zstdgpu_block_desc& bd = blocks[b];
+            DevBlock& d = B->hBlocks[b];
+            d = DevBlock{};
+            d.srcOff = bd.srcOff; d.cSize = bd.cSize; d.origSize = bd.origSize; d.frameIdx = fi;
+            d.blockType = bd.blockType; d.lastBlock = bd.lastBlock;
+            d.hufSrc = d.llSrc = d.ofSrc = d.mlSrc = SRC_NONE;
+            if (bd.blockType == BT_STOP) { d.hostLitErr = bd.hostError ? bd.hostError : (uint16_t)E_corruption; dead = true; continue; }
+            if (dead) { d.blockType = BT_STOP; d.hostLitErr = E_generic; continue; }
+            if (bd.srcOff > srcBytes || bd.cSize > srcBytes - bd.srcOff) { d.blockType = BT_STOP; d.hostLitErr = E_srcSize_wrong; dead = true; continue; }
+            if (bd.blockType != BT_COMPRESSED) continue;
+            d.hufSrc = hufDef;
+            parse_sections(src + bd.srcOff, d);
+            if (d.hostLitErr) { dead = true; continue; }
+            if (d.litType == SET_COMPRESSED) d.hufSrc = hufDef = (int32_t)b;
+            if (d.litType >= SET_COMPRESSED) {
+                d.litBufOff = litOff;
+                litOff += (d.litSize + 15) & ~15ull;
+                B->hLitJobs.push_back(b);
+            }
+            if (d.hostSeqErr) { dead = true; continue; }
+            if (d.nbSeq) {
+                if (d.llType != SET_REPEAT) llDef = (int32_t)b;
+                if (d.ofType != SET_REPEAT) ofDef = (int32_t)b;
+                if (d.mlType != SET_REPEAT) mlDef = (int32_t)b;
+                d.llSrc = llDef; d.ofSrc = ofDef; d.mlSrc = mlDef;
+                d.seqBufOff = seqOff;
+                seqOff += d.nbSeq;
+                B->hSeqJobs.push_back(b);
+            }
+        }
+    }
+    B->litBytes = litOff + 64; B->nSeqTotal = seqOff;
+    bool ok = dalloc(B->dBlocks, nBlocks, B->scratchBytes) && dalloc(B->dState, nBlocks, B->scratchBytes) &&
+              dalloc(B->dFrames, nFrames, B->scratchBytes) && dalloc(B->dStatus, nFrames, B->scratchBytes) &&
+              dalloc(B->dLitBuf, B->litBytes, B->scratchBytes) && dalloc(B->dSeqBuf, seqOff * 3 + 4, B->scratchBytes) &&
+              dalloc(B->dLitJobs, B->hLitJobs.size(), B->scratchBytes) && dalloc(B->dSeqJobs, B->hSeqJobs.size(), B->scratchBytes);
+    auto up = [&](void* d, const void* h, size_t n) { return n == 0 || hipMemcpy(d, h, n, hipMemcpyHostToDevice) == hipSuccess; };
+    ok = ok && up(B->dBlocks, B->hBlocks.data(), nBlocks * sizeof(DevBlock)) && up(B->dFrames, B->hFrames.data(), nFrames * sizeof(DevFrame)) &&
+         up(B->dLitJobs, B->hLitJobs.data(), B->hLitJobs.size() * 4) && up(B->dSeqJobs, B->hSeqJobs.data(), B->hSeqJobs.size() * 4);
+    if (!ok) { free_batch_device(B); delete B; return nullptr; }
+    return B;
+}
+
+extern "C" zstdgpu_batch* zstdgpu_batch_create_from_frames(zstdgpu_ctx* ctx, const void* hostSrc, size_t srcBytes,
+                                                           const zstdgpu_frame_in* in, uint32_t nFrames, const zstdgpu_ddict* ddict)
+{
+    std::vector<zstdgpu_frame_desc> frames(nFrames);
+    size_t const n = zstdgpu_buildDescriptors(hostSrc, srcBytes, in, nFrames, frames.data(), nullptr, 0);
+    if (iserr(n)) return nullptr;
+    std::vector<zstdgpu_block_desc> blocks(n ? n : 1);
+    size_t const n2 = zstdgpu_buildDescriptors(hostSrc, srcBytes, in, nFrames, frames.data(), blocks.data(), blocks.size());
+    if (iserr(n2)) return nullptr;
+    return zstdgpu_batch_create(ctx, hostSrc, srcBytes, frames.data(), nFrames, blocks.data(), (uint32_t)n2, ddict);
+}
+
+extern "C" void zstdgpu_batch_destroy(zstdgpu_batch* b)
+{
+    if (!b) return;
+    set_device(b->ctx);
+    free_batch_device(b);
+    delete b;
+}
+
+extern "C" size_t zstdgpu_batch_decode(zstdgpu_batch* B, const void* devSrc, void* devDst, void* stream)
+{
+    if (!B || !set_device(B->ctx)) return mkerr(E_generic);
+    hipStream_t const s = (hipStream_t)stream;
+    BatchParams p{};
+    p.src = (const uint8_t*)devSrc; p.dst = (uint8_t*)devDst;
+    p.blocks = B->dBlocks; p.state = B->dState; p.frames = B->dFrames; p.status = B->dStatus;
+    p.litBuf = B->dLitBuf; p.seqBuf = B->dSeqBuf; p.litJobs = B->dLitJobs; p.seqJobs = B->dSeqJobs;
+    p.nLitJobs = (uint32_t)B->hLitJobs.size(); p.nSeqJobs = (uint32_t)B->hSeqJobs.size();
+    p.nFrames = (uint32_t)B->hFrames.size(); p.nBlocks = (uint32_t)B->hBlocks.size();
+    if (B->ddict) {
+        p.dict = B->ddict->dDict;
+        p.dictContent = B->ddict->dBytes + B->ddict->entropySize;
+        p.dictContentSize = B->ddict->size - B->ddict->entropySize;
+    }
+    bool const prof = B->profiling && B->evReady;
+    if (prof) hipEventRecord(B->ev[0], s);
+    if (p.nBlocks) hipMemsetAsync(B->dState, 0, (size_t)p.nBlocks * sizeof(DevBlockState), s);
+    launch_literals(p, s);
+    if (prof) hipEventRecord(B->ev[1], s);
+    launch_sequences(p, s);
+    if (prof) hipEventRecord(B->ev[2], s);
+    launch_layout(p, s);
+    if (prof) hipEventRecord(B->ev[3], s);
+    launch_execute(p, s);
+    if (prof) hipEventRecord(B->ev[4], s);
+    launch_checksum(p, s);
+    if (prof) { hipEventRecord(B->ev[5], s); B->evRecorded = true; }
+    B->lastStream = s;
+    return hipGetLastError() == hipSuccess ? 0 : mkerr(E_generic);
+}
+
+extern "C" size_t zstdgpu_batch_status(zstdgpu_batch* B, zstdgpu_frame_status* status)
+{
+    if (!B || !set_device(B->ctx)) return mkerr(E_generic);
+    if (hipStreamSynchronize(B->lastStream) != hipSuccess) return mkerr(E_generic);
+    static_assert(sizeof(zstdgpu_frame_status) == sizeof(DevFrameStatus), "status layout");
+    if (status && !B->hFrames.empty() &&
+        hipMemcpy(status, B->dStatus, B->hFrames.size() * sizeof(DevFrameStatus), hipMemcpyDeviceToHost) != hipSuccess)
+        return mkerr(E_generic);
+    return 0;
+}
+
+extern "C" uint32_t zstdgpu_batch_nFrames(const zstdgpu_batch* b) { return (uint32_t)b->hFrames.size(); }
+extern "C" uint32_t zstdgpu_batch_nBlocks(const zstdgpu_batch* b) { return (uint32_t)b->hBlocks.size(); }
+extern "C" uint64_t zstdgpu_batch_srcBytes(const zstdgpu_batch* b) { return b->srcBytes; }
+extern "C" uint64_t zstdgpu_batch_scratchBytes(const zstdgpu_batch* b) { return b->scratchBytes; }
+
+extern "C" void zstdgpu_batch_set_profiling(zstdgpu_batch* B, int enabled)
+{
+    if (!B || !set_device(B->ctx)) return;
+    if (enabled && !B->evReady) {
+        bool ok = true;
+        for (auto& e : B->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
+        B->evReady = ok;
+    }
+    B->profiling = enabled != 0;
+    B->evRecorded = false;
+}
+extern "C" size_t zstdgpu_batch_stage_ms(zstdgpu_batch* B, float* ms)
+{
+    if (!B || !B->evRecorded || !set_device(B->ctx)) return mkerr(E_generic);
+    if (hipEventSynchronize(B->ev[5]) != hipSuccess) return mkerr(E_generic);
+    for (int i = 0; i < 5; i++) if (hipEventElapsedTime(&ms[i], B->ev[i], B->ev[i + 1]) != hipSuccess) return mkerr(E_generic);
+    if (hipEventElapsedTime(&ms[ZSTDGPU_STAGE_TOTAL], B->ev[0], B->ev[5]) != hipSuccess) return mkerr(E_generic);
+    return 0;
+}
+extern "C" const char* zstdgpu_stage_kernel_name(int stage)
+{
+    static const char* names[] = {"k_literals", "k_sequences", "k_layout", "k_execute", "k_checksum", "total"};
+    return stage >= 0 && stage < ZSTDGPU_NUM_STAGES ? names[stage] : "";
+}
+
+// ===================================================================== stage hooks
+extern "C" size_t zstdgpu_xxh64Batch(zstdgpu_ctx* ctx, const void* devBase, const uint64_t* off, const uint64_t* len, uint32_t n, uint64_t* digests)
+{
+    if (!ctx || !set_device(ctx)) return mkerr(E_generic);
+    if (!n) return 0;
+    uint64_t *dOff = nullptr, *dLen = nullptr, *dOut = nullptr;
+    uint64_t acct = 0;
+    size_t rc = 0;
+    if (!dalloc(dOff, n, acct) || !dalloc(dLen, n, acct) || !dalloc(dOut, n, acct)) rc = mkerr(E_memory_allocation);
+    if (!rc && (hipMemcpy(dOff, off, n * 8, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(dLen, len, n * 8, hipMemcpyHostToDevice) != hipSuccess)) rc = mkerr(E_generic);
+    if (!rc) {
+        launch_xxh64((const uint8_t*)devBase, dOff, dLen, n, dOut, nullptr);
+        if (hipMemcpy(digests, dOut, n * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = mkerr(E_generic);
+    }
+    hipFree(dOff); hipFree(dLen); hipFree(dOut);
+    return rc;
+}
+
+extern "C" size_t zstdgpu_batch_blockInfo(zstdgpu_batch* B, uint32_t bi, uint32_t* litSize, uint32_t* nbSeq, uint64_t* regenSize, uint32_t* errorCode)
+{
+    if (!B || bi >= B->hBlocks.size() || !set_device(B->ctx)) return mkerr(E_generic);
+    if (hipStreamSynchronize(B->lastStream) != hipSuccess) return mkerr(E_generic);
+    DevBlockState st;
+    if (hipMemcpy(&st, B->dState + bi, sizeof(st), hipMemcpyDeviceToHost) != hipSuccess) return mkerr(E_generic);
+    const DevBlock& d = B->hBlocks[bi];
+    if (litSize) *litSize = d.litSize;
+    if (nbSeq) *nbSeq = d.nbSeq;
+    if (regenSize) *regenSize = st.regen;
+    if (errorCode) *errorCode = d.hostLitErr ? d.hostLitErr : st.litErr ? st.litErr : d.hostSeqErr ? d.hostSeqErr : st.seqErr ? st.seqErr : st.tailErr;
+    return 0;
+}
+
+extern "C" size_t zstdgpu_batch_copyLiterals(zstdgpu_batch* B, const void* devSrc, uint32_t bi, void* out, size_t cap)
+{
+    if (!B || bi >= B->hBlocks.size() || !set_device(B->ctx)) return mkerr(E_generic);
+    if (hipStreamSynchronize(B->lastStream) != hipSuccess) return mkerr(E_generic);
+    const DevBlock& d = B->hBlocks[bi];
+    if (d.blockType != BT_COMPRESSED || d.hostLitErr) return mkerr(E_generic);
+    if (d.litSize > cap) return mkerr(E_dstSize_tooSmall);
+    if (!d.litSize) return 0;
+    if (d.litType >= SET_COMPRESSED) {
+        if (hipMemcpy(out, B->dLitBuf + d.litBufOff, d.litSize, hipMemcpyDeviceToHost) != hipSuccess) return mkerr(E_generic);
+    } else if (d.litType == SET_BASIC) {
+        if (hipMemcpy(out, (const uint8_t*)devSrc + d.srcOff + d.litHdrSize, d.litSize, hipMemcpyDeviceToHost) != hipSuccess) return mkerr(E_generic);
+    } else {
+        uint8_t v;
+        if (hipMemcpy(&v, (const uint8_t*)devSrc + d.srcOff + d.litHdrSize, 1, hipMemcpyDeviceToHost) != hipSuccess) return mkerr(E_generic);
+        memset(out, v, d.litSize);
+    }
+    return d.litSize;
+}
+
+extern "C" size_t zstdgpu_batch_copySequences(zstdgpu_batch* B, uint32_t bi, uint32_t* triples, size_t tripleCapacity)
+{
+    if (!B || bi >= B->hBlocks.size() || !set_device(B->ctx)) return mkerr(E_generic);
+    if (hipStreamSynchronize(B->lastStream) != hipSuccess) return mkerr(E_generic);
+    const DevBlock& d = B->hBlocks[bi];
+    if (d.blockType != BT_COMPRESSED || d.hostLitErr || d.hostSeqErr) return mkerr(E_generic);
+    if (d.nbSeq > tripleCapacity) return mkerr(E_dstSize_tooSmall);
+    if (!d.nbSeq) return 0;
+    DevBlockState st;
+    if (hipMemcpy(&st, B->dState + bi, sizeof(st), hipMemcpyDeviceToHost) != hipSuccess) return mkerr(E_generic);
+    if (hipMemcpy(triples, B->dSeqBuf + d.seqBufOff * 3, (size_t)d.nbSeq * 12, hipMemcpyDeviceToHost) != hipSuccess) return mkerr(E_generic);
+    for (uint32_t i = 0; i < d.nbSeq; i++) {   // offsets that referred to the incoming rep stack become concrete here
+        uint32_t const x = triples[3 * i + 2];
+        if (x & kSymbolicRep) {
+            uint32_t const v = st.repIn[(x >> 29) & 3], dl = x & ((1u << 29) - 1);
+            triples[3 * i + 2] = v > dl ? v - dl : 1;
+        }
+    }
+    return st.seqValid;
+}
+
+// ===================================================================== one-shot drop-ins
+namespace {
+
+bool ensure(uint8_t*& p, size_t& cap, size_t need)
+{
+    if (need <= cap && p) return true;
+    hipFree(p); p = nullptr; cap = 0;
+    size_t const want = need + need / 4 + 4096;
+    if (hipMalloc((void**)&p, want) != hipSuccess) { p = nullptr; return false; }
+    cap = want;
+    return true;
+}
+
+// ZSTD_decompressMultiFrame (zstd_decompressf.pas:836-942) over the batched device path.
+size_t decompress_multi(zstdgpu_ctx* ctx, void* dst, size_t dstCapacity, const void* srcv, size_t srcSize, const zstdgpu_ddict* ddict)
+{
+    if (!ctx || !set_device(ctx)) return mkerr(E_generic);
+    if (ddict && ddict->status) return mkerr(ddict->status);
+    const uint8_t* const src = (const uint8_t*)srcv;
+    if (srcSize > 0x7FFFFFFFu || dstCapacity > 0x7FFFFFFFu) { if (srcSize > 0x7FFFFFFFu) return mkerr(E_srcSize_wrong); dstCapacity = 0x7FFFFFFFu; }
+    // split into frames on the host
+    std::vector<zstdgpu_frame_in> ins;
+    std::vector<uint64_t> known;      // content size of each frame or UNKNOWN
+    size_t ip = 0;
+    size_t tailErr = 0;               // error to report once the frames before it decoded fine
+    bool more1 = false;
+    while (srcSize - ip >= 5) {
+        uint32_t const magic = rd32(src + ip);
+        if ((magic & kMagicSkipMask) == kMagicSkipStart) {
+            size_t const sk = skippable_size(src + ip, srcSize - ip);
+            if (iserr(sk)) { tailErr = sk; break; }
+            ip += sk;
+            continue;
+        }
+        size_t const fsz = zstdgpu_findFrameCompressedSize(src + ip, srcSize - ip);
+        if (iserr(fsz)) {
+            // let the walk of this (last) frame produce the precise error in decode order
+            uint32_t const code = zstdgpu_getErrorCode(fsz);
+            if (code == E_prefix_unknown && more1) { tailErr = mkerr(E_srcSize_wrong); break; }   // :917-918
+            ins.push_back({ip, srcSize - ip, 0, 0});
+            known.push_back(zstdgpu_getFrameContentSize(src + ip, srcSize - ip));
+            ip = srcSize;
+            break;
+        }
+        ins.push_back({ip, fsz, 0, 0});
+        known.push_back(zstdgpu_getFrameContentSize(src + ip, fsz));
+        ip += fsz;
+        more1 = true;
+    }
+    if (!tailErr && ip != srcSize) tailErr = mkerr(E_srcSize_wrong);   // :938-939
+    if (ins.empty()) return tailErr ? tailErr : 0;
+
+    if (!ensure(ctx->dSrc, ctx->dSrcCap, srcSize + 16) || !ensure(ctx->dDst, ctx->dDstCap, dstCapacity + 16)) return mkerr(E_memory_allocation);
+    if (hipMemcpy(ctx->dSrc, src, srcSize, hipMemcpyHostToDevice) != hipSuccess) return mkerr(E_generic);
+
+    // Frames whose content size is in the header can be placed up front and decoded together; a frame
+    // of unknown size ends a group because the next frame's offset depends on its result.
+    size_t produced = 0, i = 0;
+    while (i < ins.size()) {
+        size_t j = i;
+        size_t off = produced;
+        bool overflow = false;
+        while (j < ins.size()) {
+            ins[j].dstOff = off; ins[j].dstCapacity = dstCapacity - off;
+            uint64_t const k = known[j];
+            j++;
+            if (k == ZSTDGPU_CONTENTSIZE_UNKNOWN || k == ZSTDGPU_CONTENTSIZE_ERROR) break;
+            if (k > dstCapacity - off) { overflow = true; break; }   // this frame will report dstSize_tooSmall; later ones are never reached
+            off += (size_t)k;
+        }
+        (void)overflow;
+        uint32_t const n = (uint32_t)(j - i);
+        zstdgpu_batch* B = zstdgpu_batch_create_from_frames(ctx, src, srcSize, ins.data() + i, n, ddict);
+        if (!B) return mkerr(E_memory_allocation);
+        std::vector<zstdgpu_frame_status> st(n);
+        size_t rc = zstdgpu_batch_decode(B, ctx->dSrc, ctx->dDst, nullptr);
+        if (!rc) rc = zstdgpu_batch_status(B, st.data());
+        zstdgpu_batch_destroy(B);
+        if (rc) return rc;
+        for (uint32_t k = 0; k < n; k++) {
+            if (st[k].errorCode) {
+                if (st[k].errorCode == E_prefix_unknown && (i + k) > 0) return mkerr(E_srcSize_wrong);
+                return mkerr(st[k].errorCode);
+            }
+            produced += (size_t)st[k].regenSize;
+        }
+        i = j;
+    }
+    if (tailErr) return tailErr;
+    if (produced && hipMemcpy(dst, ctx->dDst, produced, hipMemcpyDeviceToHost) != hipSuccess) return mkerr(E_generic);
+    return produced;
+}
+
+}  // namespace
+
+extern "C" size_t zstdgpu_decompressDCtx(zstdgpu_ctx* ctx, void* dst, size_t dstCapacity, const void* src, size_t srcSize)
+{
+    return decompress_multi(ctx, dst, dstCapacity, src, srcSize, nullptr);
+}
+extern "C" size_t zstdgpu_decompress_usingDDict(zstdgpu_ctx* ctx, void* dst, size_t dstCapacity, const void* src, size_t srcSize, const zstdgpu_ddict* ddict)
+{
+    return decompress_multi(ctx, dst, dstCapacity, src, srcSize, ddict);
+}
+extern "C" size_t zstdgpu_decompress_usingDict(zstdgpu_ctx* ctx, void* dst, size_t dstCapacity, const void* src, size_t srcSize, const void* dict, size_t dictSize)
+{
+    if (!dict || !dictSize) return decompress_multi(ctx, dst, dstCapacity, src, srcSize, nullptr);
+    zstdgpu_ddict* d = zstdgpu_createDDict(ctx, dict, dictSize);
+    if (!d) return mkerr(E_memory_allocation);
+    size_t const r = decompress_multi(ctx, dst, dstCapacity, src, srcSize, d);
+    zstdgpu_freeDDict(d);
+    return r;
+}
+// ZSTD_decompress creates and frees its own context per call (zstd_decompressf.pas:977-988)
+extern "C" size_t zstdgpu_decompress(void* dst, size_t dstCapacity, const void* src, size_t srcSize)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return mkerr(E_generic);
+    zstdgpu_ctx* ctx = zstdgpu_create(dev);
+    if (!ctx) return mkerr(E_memory_allocation);
+    size_t const r = decompress_multi(ctx, dst, dstCapacity, src, srcSize, nullptr);
+    zstdgpu_destroy(ctx);
+    return r;
+}

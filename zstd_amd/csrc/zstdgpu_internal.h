@@ -1,0 +1,113 @@
+// Structures shared by the host library and the gfx950 kernels.
+#pragma once
+#include <stdint.h>
+
+namespace zg {
+
+// ZSTD_ErrorCode values (common/error_private.pas:6-36)
+enum : uint32_t {
+    E_none = 0, E_generic = 1, E_prefix_unknown = 10, E_frameParameter_unsupported = 14,
+    E_frameParameter_windowTooLarge = 16, E_corruption = 20, E_checksum_wrong = 22,
+    E_dictionary_corrupted = 30, E_dictionary_wrong = 32, E_memory_allocation = 64,
+    E_dstSize_tooSmall = 70, E_srcSize_wrong = 72, E_maxCode = 120
+};
+
+enum : int32_t { SRC_DICT = -1, SRC_NONE = -2 };
+enum : uint8_t { BT_RAW = 0, BT_RLE = 1, BT_COMPRESSED = 2, BT_STOP = 3 };   // BT_STOP: walk ended here with an error
+enum : uint8_t { SET_BASIC = 0, SET_RLE = 1, SET_COMPRESSED = 2, SET_REPEAT = 3 };  // symbolEncodingType_e (zstd_internal.pas:112-118)
+
+constexpr uint32_t kBlockSizeMax = 1u << 17;
+constexpr uint32_t kSymbolicRep = 0x80000000u;   // sequence offset / rep value that refers to the block's incoming rep stack
+
+// Per-block descriptor consumed by the kernels (built on the host).
+struct DevBlock {
+    uint64_t srcOff;       // block payload in the source buffer
+    uint64_t litBufOff;    // decoded literals go here (litType compressed/repeat)
+    uint64_t seqBufOff;    // first sequence slot of this block
+    uint32_t cSize;
+    uint32_t origSize;     // raw/RLE regenerated size
+    uint32_t frameIdx;
+    uint32_t litSize;      // regenerated literal bytes
+    uint32_t litCSize;     // literal payload bytes after the literals header
+    uint32_t nbSeq;
+    uint32_t seqHdrOff;    // payload offset of the first table description (after the modes byte)
+    int32_t  hufSrc;       // block whose literals header carries the Huffman table in use; SRC_DICT / SRC_NONE
+    int32_t  llSrc, ofSrc, mlSrc;   // block that defines each sequence table in use; SRC_DICT / SRC_NONE
+    uint16_t hostLitErr;   // error found on the host before/inside the literals header
+    uint16_t hostSeqErr;   // error found on the host in the sequences header
+    uint8_t  blockType;
+    uint8_t  lastBlock;
+    uint8_t  litType;
+    uint8_t  litHdrSize;
+    uint8_t  singleStream;
+    uint8_t  llType, ofType, mlType;
+};
+
+// Per-block results written by the kernels.
+struct DevBlockState {
+    uint64_t regen;        // stage 1: litSize + sum(matchLength); stage 2 fills it for raw/RLE/no-sequence blocks
+    uint64_t dstOff;       // stage 2: offset of the block inside its frame's output
+    uint32_t litErr;       // stage 0
+    uint32_t seqErr;       // stage 1: table description / bitstream init errors
+    uint32_t seqValid;     // stage 1: sequences decoded before the bitstream ran dry
+    uint32_t tailErr;      // stage 1: bitstream not consumed exactly
+    uint32_t repOut[3];    // stage 1: rep stack after the block (entries may be symbolic)
+    uint32_t repIn[3];     // stage 2: rep stack entering the block (concrete)
+    uint32_t err;          // stage 3: verdict for the block
+    uint32_t pad;
+};
+
+struct DevFrame {
+    uint64_t dstOff, dstCapacity, contentSize;
+    uint32_t firstBlock, nBlocks;
+    uint32_t checksumFlag, checksum;
+    uint32_t hostError;
+    uint32_t useDict;      // 1: the batch dictionary applies to this frame
+};
+
+struct DevFrameStatus {    // same layout as zstdgpu_frame_status
+    uint32_t errorCode, xxh64Low32;
+    uint64_t regenSize;
+};
+
+// Digested dictionary in device memory (ZSTD_entropyDTables_t image in this library's cell formats).
+constexpr uint32_t kHufCells = 1u << 12;      // HUF_TABLELOG_MAX
+struct DevDict {
+    uint32_t status;        // 0 ok, else ZSTD_ErrorCode (dictionary_corrupted)
+    uint32_t hasEntropy;    // 1: tables below are valid (magic dictionary); 0: raw-content dictionary
+    uint32_t entropySize;   // bytes before the content
+    uint32_t hufLog;
+    uint32_t llLog, ofLog, mlLog;
+    uint32_t rep[3];
+    uint32_t pad[2];
+    uint16_t huf[kHufCells];   // {byte, nbBits<<8}
+    uint32_t ll[512], of[256], ml[512];   // packed sequence cells
+};
+
+struct BatchParams {
+    const uint8_t* src;          // device source buffer
+    uint8_t* dst;                // device destination buffer
+    const DevBlock* blocks;
+    DevBlockState* state;
+    const DevFrame* frames;
+    DevFrameStatus* status;
+    uint8_t* litBuf;
+    uint32_t* seqBuf;            // triples (litLength, matchLength, offset)
+    const uint32_t* litJobs;     // block indices with Huffman-coded literals
+    const uint32_t* seqJobs;     // block indices with nbSeq > 0
+    const DevDict* dict;         // may be null
+    const uint8_t* dictContent;  // device pointer to dictionary content
+    uint32_t dictContentSize;
+    uint32_t nLitJobs, nSeqJobs, nFrames, nBlocks;
+};
+
+// kernel launchers (kernels.hip)
+void launch_literals(const BatchParams& p, void* stream);
+void launch_sequences(const BatchParams& p, void* stream);
+void launch_layout(const BatchParams& p, void* stream);
+void launch_execute(const BatchParams& p, void* stream);
+void launch_checksum(const BatchParams& p, void* stream);
+void launch_digest_dict(const uint8_t* devDict, uint32_t dictSize, DevDict* out, void* stream);
+void launch_xxh64(const uint8_t* base, const uint64_t* off, const uint64_t* len, uint32_t n, uint64_t* out, void* stream);
+
+}  // namespace zg
