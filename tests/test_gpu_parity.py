@@ -88,7 +88,7 @@ def test_batch_mixed_valid_and_corrupt(dctx, via_descriptors):
     """One launch over every dictionary-less single-frame fixture, valid and corrupt together: each
     frame gets its own verdict, a corrupt neighbour does not disturb a valid frame."""
     entries = [e for e in FRAMES if "dict" not in e and e["capacity"] <= (1 << 20)
-               and not e["name"].startswith(("concat", "skippable", "rec_nodict"))]
+               and not e["name"].startswith(("concat", "skippable", "rec_nodict")) and e["csize"] > 0]   # a batch entry is exactly one frame
     b, d_src, fin, st, out = run_batch(dctx, entries, via_descriptors=via_descriptors)
     for i, e in enumerate(entries):
         want, werr = oracle.decompress(read_frame(e), e["capacity"])

@@ -29,6 +29,7 @@ DEVI uint32_t hb32(uint32_t v) { return 31u - (uint32_t)__builtin_clz(v); }
 DEVI void wave_sync()
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
