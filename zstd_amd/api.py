@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libzstdgpu.so")
+LIB_PATH = os.environ.get("ZSTDGPU_LIB") or os.path.join(_HERE, "libzstdgpu.so")   # ZSTDGPU_LIB: a diagnostic build of the same library
 
 CONTENTSIZE_UNKNOWN = (1 << 64) - 1
 CONTENTSIZE_ERROR = (1 << 64) - 2

@@ -34,6 +34,14 @@ DEVI void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+// LDS-only ordering between the lanes of this wave: LDS operations of a wave complete in issue order,
+// so draining lgkmcnt is enough; outstanding global loads and stores are deliberately not waited for.
+DEVI void lds_sync()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
 DEVI uint64_t ld_u64(const uint8_t* p)
 {
     uint64_t v;
@@ -90,6 +98,33 @@ struct BitR {
         return v;
     }
 };
+
+// Bit cursor of the two hot loops.  The loops never touch global memory: a lane group first stages the
+// top of the unread stream into an LDS window (aligned 16-byte units, coalesced), then one lane
+// decodes a bounded number of symbols from that window.  (Vector-memory loads and stores inside the
+// loop would serialise it, because a wave's loads and stores retire in issue order.)
+// The cursor Q counts the window bits below the next unread bit; a 64-bit peek at Q takes three
+// window dwords and two v_alignbit, fields come out with v_bfe, and nothing is renormalised.
+DEVI void peek64(const uint32_t* win, uint32_t Q, uint32_t& tHi, uint32_t& tLo)
+{
+    uint32_t const d = Q >> 5, sft = Q & 31;
+    uint32_t const a0 = win[d - 2], a1 = win[d - 1], a2 = win[d];
+    tHi = __builtin_amdgcn_alignbit(a2, a1, sft);
+    tLo = __builtin_amdgcn_alignbit(a1, a0, sft);
+}
+// top 32 bits of ({hi,lo} << n), n in [0,63]
+DEVI uint32_t shl_hi(uint32_t hi, uint32_t lo, uint32_t n) { return (uint32_t)(((((uint64_t)hi << 32) | lo) << n) >> 32); }
+// `n` bits of t that start `skip` bits below its top: skip + n <= 32, n == 0 gives 0
+DEVI uint32_t take(uint32_t t, uint32_t skip, uint32_t n) { return __builtin_amdgcn_ubfe(t, 32 - skip - n, n); }
+
+// 16 bytes at `addr` (16-byte aligned), clamped to `floor` (the source buffer's first byte) so a window
+// that reaches below the buffer reads the buffer's first bytes instead; such bytes lie below the
+// stream start and are never legitimately consumed.  Upward a unit ends at most 15 bytes past the last
+// byte of a stream, inside the same 16-byte line of the source buffer's last page.
+DEVI uint4 ld_unit(uintptr_t addr, uintptr_t floor)
+{
+    return *(const uint4*)(addr >= floor ? addr : floor);
+}
 
 // ---------------------------------------------------------------- FSE_readNCount (entropy_common.pas:83-256)
 constexpr uint32_t kFail = 0xFFFFFFFFu;
@@ -284,29 +319,41 @@ DEVI uint32_t dev_huf_read_table_desc(const uint8_t* src, uint32_t srcSize, Byte
 }
 
 // ---------------------------------------------------------------- stage 0: literals
-constexpr int kHufLanes = 8;                 // lanes per literal job (4 streams + helpers for the table fill)
+
+constexpr int kHufLanes = 16;                // lanes per literal job: 4 decode one stream each, all 16 move data
 constexpr int kHufJobs = 64 / kHufLanes;     // jobs per wave
 constexpr uint32_t kHufTabBytes = 8192;      // 2^12 cells of {byte, nbBits}
-constexpr uint32_t kHufAuxBytes = 1024;      // weights[256] | pos[256] u16 | rank[13] u32
-constexpr uint32_t kHufJobBytes = kHufTabBytes + kHufAuxBytes;
+constexpr uint32_t kHufRound = 128;          // symbols per stream per round
+constexpr uint32_t kHufInDw = 96;            // staged input per stream per round (24 units): 128 symbols x <=12 bits + alignment slack
+constexpr uint32_t kHufStageBytes = 4 * 4 * kHufInDw + 4 * kHufRound;   // 4 windows + 4 output stages = 2048
+constexpr uint32_t kHufJobBytes = kHufTabBytes + kHufStageBytes;        // the table-build scratch (weights/pos/rank, 820 B) shares the stage area
 
-// one backward stream -> `n` bytes at `out` (HUF_decodeStreamX1 + the BIT_endOfDStream check, huf_decompress.pas:301-349, :553-555)
-DEVI bool huf_decode_stream(const uint16_t* cells, uint32_t tableLog, const uint8_t* s, uint32_t size, uint8_t* out, uint32_t n)
+// Stream geometry of a literals section as scalars (arrays indexed by a lane-dependent stream number
+// would live in scratch memory): stream k reads sOff(k)..+sSize(k) and writes oCnt(k) bytes at k * seg.
+struct HufGeo {
+    uint32_t l1, l2, l3, l4;   // compressed stream sizes
+    uint32_t seg, lastCnt;     // bytes regenerated by streams 0..2 and by stream 3
+    uint32_t first;            // offset of stream 0 (after the jump table)
+    DEVI uint32_t sOff(uint32_t k) const { return first + (k > 0 ? l1 : 0u) + (k > 1 ? l2 : 0u) + (k > 2 ? l3 : 0u); }
+    DEVI uint32_t sSize(uint32_t k) const { return k == 0 ? l1 : k == 1 ? l2 : k == 2 ? l3 : l4; }
+    DEVI uint32_t oCnt(uint32_t k) const { return k < 3 ? seg : lastCnt; }
+};
+
+// flush up to kHufRound decoded bytes per stream from the LDS stages to the literal buffer: 32 units, 2 per lane
+DEVI void huf_flush(uint8_t* out, const uint8_t* outStage, const HufGeo& g, uint32_t pr, uint32_t nStreams, uint32_t gl)
 {
-    BitR br;
-    if (!br.init(s, size)) return false;
-    uint32_t const shift = 64 - tableLog;
-    for (uint32_t i = 0; i < n; i++) {
-        if (br.c > 52) {
-            if (br.left() < 0) return false;
-            br.refill();
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        uint32_t const u = gl + 16 * h, k = u >> 3, part = u & 7;
+        uint32_t const oc = g.oCnt(k);
+        uint32_t const cnt = oc > pr ? (oc - pr < kHufRound ? oc - pr : kHufRound) : 0;
+        if (k < nStreams && 16 * part < cnt) {
+            uint8_t* const d = out + k * g.seg + pr + 16 * part;
+            const uint8_t* const sp = outStage + k * kHufRound + 16 * part;
+            if (16 * part + 16 <= cnt) { uint4 const x = *(const uint4*)sp; __builtin_memcpy(d, &x, 16); }
+            else for (uint32_t i = 0; i < cnt - 16 * part; i++) d[i] = sp[i];
         }
-        uint32_t const idx = (uint32_t)((br.w << br.c) >> shift);
-        uint32_t const cell = cells[idx];
-        br.c += (int)(cell >> 8);
-        out[i] = (uint8_t)cell;
     }
-    return br.left() == 0;
 }
 
 __global__ __launch_bounds__(64) void k_literals(BatchParams p)
@@ -320,9 +367,11 @@ __global__ __launch_bounds__(64) void k_literals(BatchParams p)
     DevBlock const blk = p.blocks[b];
     uint8_t* const tab = lds + sub * kHufJobBytes;
     uint16_t* const cells = (uint16_t*)tab;
-    uint8_t* const weights = tab + kHufTabBytes;
+    uint8_t* const weights = tab + kHufTabBytes;                       // table-build scratch, dead once the table is filled
     uint16_t* const pos = (uint16_t*)(tab + kHufTabBytes + 256);
     uint32_t* const rank = (uint32_t*)(tab + kHufTabBytes + 768);
+    uint32_t* const inWin = (uint32_t*)(tab + kHufTabBytes);          // [4][kHufInDw] dwords
+    uint8_t* const outStage = tab + kHufTabBytes + 4 * 4 * kHufInDw;  // [4][kHufRound] bytes
 
     uint32_t err = 0, tableLog = 0, nbSymbols = 0, hSize = 0;
     bool const fromDict = (blk.hufSrc == SRC_DICT);
@@ -363,42 +412,116 @@ __global__ __launch_bounds__(64) void k_literals(BatchParams p)
         }
     }
     wave_sync();
+
+    // ---- stream geometry, known to every lane of the group (huf_decompress.pas:406-421)
+    uint32_t const tabHdr = (blk.litType == SET_COMPRESSED) ? hSize : 0;
+    const uint8_t* const cs = p.src + blk.srcOff + blk.litHdrSize + tabHdr;
+    uint32_t const csize = blk.litCSize - tabHdr;
+    uint8_t* const out = p.litBuf + blk.litBufOff;
+    uint32_t const nStreams = blk.singleStream ? 1u : 4u;
+    HufGeo g = {0, 0, 0, 0, 0, 0, 0};
     if (ok) {
-        uint32_t const tabHdr = (blk.litType == SET_COMPRESSED) ? hSize : 0;
-        const uint8_t* const cs = p.src + blk.srcOff + blk.litHdrSize + tabHdr;
-        uint32_t const csize = blk.litCSize - tabHdr;
-        uint8_t* const out = p.litBuf + blk.litBufOff;
-        if (blk.singleStream) {
-            if (sl == 0) ok = huf_decode_stream(cells, tableLog, cs, csize, out, blk.litSize);
-        } else {
-            // 4 streams: 6-byte jump table, segment = (litSize+3)/4 (huf_decompress.pas:406-421)
-            if (csize < 10) ok = false;
-            else {
-                uint32_t const l1 = cs[0] | (cs[1] << 8), l2 = cs[2] | (cs[3] << 8), l3 = cs[4] | (cs[5] << 8);
-                uint32_t const seg = (blk.litSize + 3) / 4;
-                if (l1 + l2 + l3 + 6 > csize || 3 * seg > blk.litSize) ok = false;
-                else if (sl < 4) {
-                    uint32_t const l4 = csize - 6 - l1 - l2 - l3;
-                    uint32_t const so = 6 + (sl > 0 ? l1 : 0) + (sl > 1 ? l2 : 0) + (sl > 2 ? l3 : 0);
-                    uint32_t const ssz = sl == 0 ? l1 : sl == 1 ? l2 : sl == 2 ? l3 : l4;
-                    uint32_t const oo = sl * seg;
-                    uint32_t const on = sl < 3 ? seg : blk.litSize - 3 * seg;
-                    ok = huf_decode_stream(cells, tableLog, cs + so, ssz, out + oo, on);
-                }
-            }
+        if (blk.singleStream) { g.l1 = csize; g.seg = blk.litSize; }
+        else if (csize < 10) ok = false;
+        else {
+            g.l1 = cs[0] | (cs[1] << 8); g.l2 = cs[2] | (cs[3] << 8); g.l3 = cs[4] | (cs[5] << 8);
+            g.seg = (blk.litSize + 3) / 4;
+            g.first = 6;
+            if (g.l1 + g.l2 + g.l3 + 6 > csize || 3 * g.seg > blk.litSize) ok = false;   // 4th segment must start inside the literal buffer
+            else { g.l4 = csize - 6 - g.l1 - g.l2 - g.l3; g.lastCnt = blk.litSize - 3 * g.seg; }
         }
     }
-    unsigned long long const bad = __ballot(!ok);
+    // ---- per-lane stream state (lanes 0..3 of the group own a stream)
+    uint32_t const mySize = g.sSize(sl & 3), myCnt = g.oCnt(sl & 3);
+    const uint8_t* const myStart = cs + g.sOff(sl & 3);
+    int bitsLeft = 0;
+    bool bad = !ok;
+    if (ok && sl < nStreams) {
+        // BIT_initDStream (bitstream.pas:206-275): empty stream or missing end mark is an error
+        if (mySize == 0) bad = true;
+        else {
+            uint32_t const last = myStart[mySize - 1];
+            if (last == 0) bad = true;
+            else bitsLeft = (int)(mySize * 8) - (int)(8 - hb32(last));
+        }
+    }
+    uint32_t const maxCnt = ok ? g.seg : 0;       // stream 0 is never shorter than the others
+    uintptr_t const floorAddr = (uintptr_t)p.src;
+    uint32_t const shift = 32 - tableLog;
+    uint32_t done = 0;                            // symbols of my stream already decoded
+    for (uint32_t r0 = 0; r0 < maxCnt; r0 += kHufRound) {
+        // 1. stage: 4 windows x 24 aligned 16-byte units, 6 per lane
+        uintptr_t wb[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            int const bl = __shfl(bitsLeft, lead + k);
+            uintptr_t const top = (uintptr_t)(cs + g.sOff(k)) + (uintptr_t)((bl > 0 ? bl + 7 : 0) >> 3);
+            wb[k] = ((top + 15) & ~(uintptr_t)15) - 4 * kHufInDw;
+        }
+        uint4 v[6];
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            uint32_t const u = sl + 16 * j, k = (u * 43u) >> 10, iu = u - 24 * k;    // u / 24 for u < 96
+            uintptr_t const base = k == 0 ? wb[0] : k == 1 ? wb[1] : k == 2 ? wb[2] : wb[3];
+            v[j] = ld_unit(base + 16 * iu, floorAddr);
+        }
+        // 2. flush the previous round's bytes (stores younger than the loads above: not waited for in this round)
+        if (r0 > 0) huf_flush(out, outStage, g, r0 - kHufRound, nStreams, sl);
+        lds_sync();     // the flush has read the stages
+#pragma unroll
+        for (int j = 0; j < 6; j++) *(uint4*)(inWin + 4 * (sl + 16 * j)) = v[j];
+        lds_sync();
+        // 3. decode up to 128 symbols of my stream, LDS only (HUF_decodeStreamX1, huf_decompress.pas:301-349)
+        if (sl < nStreams && !bad && done < myCnt) {
+            uint32_t const n = myCnt - done < kHufRound ? myCnt - done : kHufRound;
+            uintptr_t const mywb = sl == 0 ? wb[0] : sl == 1 ? wb[1] : sl == 2 ? wb[2] : wb[3];
+            int const Qbase = (int)(8 * (int64_t)((uintptr_t)myStart - mywb));
+            uint32_t Q = (uint32_t)(Qbase + bitsLeft);       // >= 1409: a round consumes <= 1536 bits of a window that holds >= 2945
+            const uint32_t* const win = inWin + sl * kHufInDw;
+            uint32_t* const so = (uint32_t*)(outStage + sl * kHufRound);
+            uint32_t i = 0;
+            for (; i + 4 <= n; i += 4) {     // 4 symbols (<= 48 bits) per 64-bit peek
+                uint32_t tHi, tLo;
+                peek64(win, Q, tHi, tLo);
+                uint32_t const c0 = cells[tHi >> shift];
+                uint32_t pbits = c0 >> 8;
+                uint32_t const c1 = cells[shl_hi(tHi, tLo, pbits) >> shift];
+                pbits += c1 >> 8;
+                uint32_t const c2 = cells[shl_hi(tHi, tLo, pbits) >> shift];
+                pbits += c2 >> 8;
+                uint32_t const c3 = cells[shl_hi(tHi, tLo, pbits) >> shift];
+                pbits += c3 >> 8;
+                so[i >> 2] = (c0 & 0xFF) | ((c1 & 0xFF) << 8) | ((c2 & 0xFF) << 16) | (c3 << 24);
+                Q -= pbits;
+            }
+            for (; i < n; i++) {
+                uint32_t tHi, tLo;
+                peek64(win, Q, tHi, tLo);
+                uint32_t const c0 = cells[tHi >> shift];
+                ((uint8_t*)so)[i] = (uint8_t)c0;
+                Q -= c0 >> 8;
+            }
+            bitsLeft = (int)Q - Qbase;
+            done += n;
+        }
+        lds_sync();
+    }
+    if (maxCnt > 0) huf_flush(out, outStage, g, ((maxCnt - 1) / kHufRound) * kHufRound, nStreams, sl);
+    // every stream must end exactly at its first bit (BIT_endOfDStream, huf_decompress.pas:553-555)
+    if (sl < nStreams && !bad && bitsLeft != 0) bad = true;
+    unsigned long long const anyBad = __ballot(bad);
     if (sl == 0) {
-        uint32_t const mine = (uint32_t)((bad >> lead) & ((1u << kHufLanes) - 1));
+        uint32_t const mine = (uint32_t)((anyBad >> lead) & ((1u << kHufLanes) - 1));
         p.state[b].litErr = err ? err : (mine ? (uint32_t)E_corruption : 0u);
     }
 }
 
 // ---------------------------------------------------------------- sequence tables
-// Packed decoding cell of a sequence table: nextState base (9 bits) | nbBits (4) << 9 | symbol code (6) << 13.
-// Base value and extra-bit count of a code come from small side tables (LL/ML) or arithmetic (OF).
-DEVI uint32_t seq_cell(uint32_t nextState, uint32_t nbBits, uint32_t code) { return nextState | (nbBits << 9) | (code << 13); }
+// Packed decoding cell of a sequence table:
+//   nextState base (9 bits) | nbBits (4) << 9 | nbAdditionalBits (5) << 13 | symbol code (6) << 18.
+// Everything the bit cursor depends on is in the cell; the base value of a code comes from a small LDS
+// side table (LL/ML) or arithmetic (OF) off the serial chain.
+DEVI uint32_t seq_cell(uint32_t nextState, uint32_t nbBits, uint32_t addBits, uint32_t code) { return nextState | (nbBits << 9) | (addBits << 13) | (code << 18); }
 
 __constant__ uint32_t c_LL_base[36] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18, 20, 22, 24, 28, 32, 40,
                                        48, 64, 0x80, 0x100, 0x200, 0x400, 0x800, 0x1000, 0x2000, 0x4000, 0x8000, 0x10000};
@@ -419,11 +542,12 @@ __constant__ int16_t c_OF_defaultNorm[29] = {1, 1, 1, 1, 1, 1, 2, 2, 2, 1, 1, 1,
 
 enum { T_LL = 0, T_OF = 1, T_ML = 2 };
 DEVI uint32_t tbl_max(int t) { return t == T_LL ? 35u : t == T_OF ? 31u : 52u; }
+DEVI uint32_t tbl_addBits(int t, uint32_t code) { return t == T_LL ? c_LL_bits[code] : t == T_OF ? code : c_ML_bits[code]; }
 DEVI uint32_t tbl_maxLog(int t) { return t == T_OF ? 8u : 9u; }
 
 // ZSTD_buildFSETable_body (zstd_decompress_block.pas:436-583) into packed cells.  `norm` holds maxSV+1 counts.
 template <typename CellPtr, typename NormPtr, typename NextPtr>
-DEVI void dev_build_seq_table(CellPtr cells, NormPtr norm, NextPtr symNext, uint32_t maxSV, uint32_t tableLog)
+DEVI void dev_build_seq_table(int t, CellPtr cells, NormPtr norm, NextPtr symNext, uint32_t maxSV, uint32_t tableLog)
 {
     uint32_t const tableSize = 1u << tableLog;
     uint32_t highThreshold = tableSize - 1;
@@ -446,7 +570,7 @@ DEVI void dev_build_seq_table(CellPtr cells, NormPtr norm, NextPtr symNext, uint
         uint32_t const ns = symNext[sym];
         symNext[sym] = (uint16_t)(ns + 1);
         uint32_t const nb = tableLog - hb32(ns);
-        cells[u] = seq_cell((ns << nb) - tableSize, nb, sym);
+        cells[u] = seq_cell((ns << nb) - tableSize, nb, tbl_addBits(t, sym), sym);
     }
 }
 
@@ -456,11 +580,12 @@ DEVI void dev_build_seq_table(CellPtr cells, NormPtr norm, NextPtr symNext, uint
 template <typename CellPtr, typename NormPtr, typename NextPtr>
 DEVI uint32_t dev_build_from_desc(int t, uint32_t type, const uint8_t* ptr, uint32_t avail, CellPtr cells, NormPtr norm, NextPtr symNext, uint32_t& log)
 {
+    if (type == SET_REPEAT) return kFail;   // callers resolve repeat mode to the defining block first
     if (type == SET_RLE) {
         if (avail < 1) return kFail;
         uint32_t const sym = ptr[0];
         if (sym > tbl_max(t)) return kFail;
-        cells[0] = seq_cell(0, 0, sym);
+        cells[0] = seq_cell(0, 0, tbl_addBits(t, sym), sym);
         log = 0;
         return 1;
     }
@@ -469,7 +594,7 @@ DEVI uint32_t dev_build_from_desc(int t, uint32_t type, const uint8_t* ptr, uint
         if (t == T_LL) { maxSV = 35; log = 6; for (uint32_t s = 0; s <= maxSV; s++) norm[s] = c_LL_defaultNorm[s]; }
         else if (t == T_OF) { maxSV = 28; log = 5; for (uint32_t s = 0; s <= maxSV; s++) norm[s] = c_OF_defaultNorm[s]; }
         else { maxSV = 52; log = 6; for (uint32_t s = 0; s <= maxSV; s++) norm[s] = c_ML_defaultNorm[s]; }
-        dev_build_seq_table(cells, norm, symNext, maxSV, log);
+        dev_build_seq_table(t, cells, norm, symNext, maxSV, log);
         return 0;
     }
     // SET_COMPRESSED
@@ -477,7 +602,7 @@ DEVI uint32_t dev_build_from_desc(int t, uint32_t type, const uint8_t* ptr, uint
     uint32_t const h = dev_readNCount(norm, maxSV, tableLog, ptr, avail);
     if (h == kFail) return kFail;
     if (tableLog > tbl_maxLog(t)) return kFail;
-    dev_build_seq_table(cells, norm, symNext, maxSV, tableLog);
+    dev_build_seq_table(t, cells, norm, symNext, maxSV, tableLog);
     log = tableLog;
     return h;
 }
@@ -494,15 +619,12 @@ DEVI uint32_t dev_desc_size(int t, uint32_t type, const uint8_t* payload, uint32
 }
 
 // ---------------------------------------------------------------- stage 1: sequences
-constexpr int kSeqJobs = 4;                 // jobs per wave; the job runs on the first lane of its 16-lane group
-constexpr uint32_t kSeqJobWords = 512 + 512 + 256 + 64;   // LL | ML | OF cells + {norm[64] i16, symNext[64] u16}
+constexpr int kSeqJobs = 4;                 // jobs per wave: a 16-lane group each; its first lane decodes, all 16 move data
+constexpr uint32_t kSeqRound = 64;          // sequences per round
+constexpr uint32_t kSeqInDw = 192;          // staged input per round, 16-byte units: 64 x <=89 bits + state init + alignment slack (a peek may also read, and ignore, the dword after it)
+constexpr uint32_t kSeqJobWords = 512 + 512 + 256 + 64 + kSeqInDw + 4 * kSeqRound;   // LL | ML | OF cells, {norm, symNext}, input window, record ring
 constexpr uint32_t kRepIdxShift = 29;
 
-DEVI uint32_t rep_dec1(uint32_t x)   // "rep[0] - 1, but never 0" (zstd_decompress_block.pas:1150-1154) on a possibly symbolic value
-{
-    if (x & kSymbolicRep) return x + 1;
-    return x == 1 ? 1 : x - 1;
-}
 DEVI uint32_t rep_resolve(uint32_t x, const uint32_t* repIn)
 {
     if (!(x & kSymbolicRep)) return x;
@@ -511,12 +633,46 @@ DEVI uint32_t rep_resolve(uint32_t x, const uint32_t* repIn)
     return v > d ? v - d : 1;
 }
 
+// A repeat-offset stack entry is either a concrete offset or "slot k of some earlier stack, minus d
+// (never below 1)".  Substituting the earlier stack (p0,p1,p2) composes two such descriptions; the
+// operation is associative, which lets the stack after every sequence be found with a prefix scan.
+DEVI uint32_t rep_subst(uint32_t e, uint32_t p0, uint32_t p1, uint32_t p2)
+{
+    uint32_t const k = (e >> kRepIdxShift) & 3, d = e & ((1u << kRepIdxShift) - 1);
+    uint32_t const x = k == 0 ? p0 : k == 1 ? p1 : p2;
+    uint32_t const r = (x & kSymbolicRep) ? x + d : (x > d ? x - d : 1u);
+    return (e & kSymbolicRep) ? r : e;
+}
+struct Rep3 { uint32_t a, b, c; };
+DEVI Rep3 rep_compose(Rep3 first, Rep3 then)   // apply `first`, then `then`
+{
+    Rep3 r;
+    r.a = rep_subst(then.a, first.a, first.b, first.c);
+    r.b = rep_subst(then.b, first.a, first.b, first.c);
+    r.c = rep_subst(then.c, first.a, first.b, first.c);
+    return r;
+}
+constexpr uint32_t kSlot0 = kSymbolicRep | (0u << kRepIdxShift), kSlot1 = kSymbolicRep | (1u << kRepIdxShift), kSlot2 = kSymbolicRep | (2u << kRepIdxShift);
+
+// Sequence records written by this stage, 16 bytes each, nbSeq + 1 per block:
+//   {offset (possibly symbolic), output position, literal position, litLength}, positions block-relative;
+//   the extra last record carries the end positions, so matchLength = next.outPos - outPos - litLength.
+//
+// Work split inside a 16-lane group, in rounds of 64 sequences:
+//   leader lane   the serial chain only: 3 table cells -> 6 bit widths -> bit cursor -> 3 next states
+//                 (ZSTD_decodeSequence's state half, zstd_decompress_block.pas:1092-1101, :1220-1225)
+//   all 16 lanes  4 sequences each: extra bits, base values, repeat-offset resolution by prefix scan,
+//                 positions by prefix sum, coalesced record stores (:1105-1180)
 __global__ __launch_bounds__(64) void k_sequences(BatchParams p)
 {
     __shared__ __attribute__((aligned(16))) uint32_t lds[kSeqJobs * kSeqJobWords];
+    __shared__ uint32_t sLLbase[36], sMLbase[53];
     uint32_t const lane = threadIdx.x;
-    uint32_t const sub = lane >> 4;
-    if (lane & 15) return;
+    if (lane < 36) sLLbase[lane] = c_LL_base[lane];
+    if (lane < 53) sMLbase[lane] = c_ML_base[lane];
+    wave_sync();
+    uint32_t const sub = lane >> 4, gl = lane & 15, lead = lane & ~15u;
+    bool const leader = (gl == 0);
     uint32_t const job = blockIdx.x * kSeqJobs + sub;
     if (job >= p.nSeqJobs) return;
     uint32_t const b = p.seqJobs[job];
@@ -526,108 +682,252 @@ __global__ __launch_bounds__(64) void k_sequences(BatchParams p)
     uint32_t* const tOF = tML + 512;
     int16_t* const norm = (int16_t*)(tOF + 256);
     uint16_t* const symNext = (uint16_t*)(norm + 64);
+    uint32_t* const inWin = tOF + 256 + 64;
+    uint32_t* const ring = inWin + kSeqInDw;
     DevBlockState* const st = p.state + b;
 
+#ifdef ZG_STAMPS
+    uint64_t const stamp0 = __builtin_readcyclecounter();
+    uint64_t stampLoop = 0;
+#endif
     const uint8_t* const payload = p.src + blk.srcOff;
     uint32_t off = blk.seqHdrOff;
-    uint32_t logs[3] = {0, 0, 0};
-    bool fail = false;
+    uint32_t logLL = 0, logOF = 0, logML = 0;
+    uint32_t failU = 0;
+    if (leader) {
+        uint32_t logs[3] = {0, 0, 0};
+        bool fail = false;
 #pragma unroll
-    for (int t = 0; t < 3; t++) {
-        uint32_t const type = t == T_LL ? blk.llType : t == T_OF ? blk.ofType : blk.mlType;
-        int32_t const srcB = t == T_LL ? blk.llSrc : t == T_OF ? blk.ofSrc : blk.mlSrc;
-        uint32_t* const cells = t == T_LL ? tLL : t == T_OF ? tOF : tML;
-        if (fail) break;
-        if (type != SET_REPEAT) {
-            if (off > blk.cSize) { fail = true; break; }
-            uint32_t const h = dev_build_from_desc(t, type, payload + off, blk.cSize - off, cells, norm, symNext, logs[t]);
-            if (h == kFail) { fail = true; break; }
-            off += h;
-        } else if (srcB == SRC_NONE) {
-            fail = true;
-        } else if (srcB == SRC_DICT) {
-            const uint32_t* const dc = t == T_LL ? p.dict->ll : t == T_OF ? p.dict->of : p.dict->ml;
-            uint32_t const lg = t == T_LL ? p.dict->llLog : t == T_OF ? p.dict->ofLog : p.dict->mlLog;
-            for (uint32_t u = 0; u < (1u << lg); u++) cells[u] = dc[u];
-            logs[t] = lg;
-        } else {
-            // rebuild from the block that defined the table: walk its descriptions up to table t
-            DevBlock const sb = p.blocks[srcB];
-            const uint8_t* const sp = p.src + sb.srcOff;
-            uint32_t o = sb.seqHdrOff;
-            for (int u = 0; u < t && !fail; u++) {
-                uint32_t const ut = u == T_LL ? sb.llType : sb.ofType;
-                uint32_t const sz = dev_desc_size(u, ut, sp, o, sb.cSize, norm);
-                if (sz == kFail) fail = true; else o += sz;
-            }
-            if (!fail) {
-                uint32_t const stype = t == T_LL ? sb.llType : t == T_OF ? sb.ofType : sb.mlType;
-                if (o > sb.cSize || dev_build_from_desc(t, stype, sp + o, sb.cSize - o, cells, norm, symNext, logs[t]) == kFail) fail = true;
+        for (int t = 0; t < 3; t++) {
+            uint32_t const type = t == T_LL ? blk.llType : t == T_OF ? blk.ofType : blk.mlType;
+            int32_t const srcB = t == T_LL ? blk.llSrc : t == T_OF ? blk.ofSrc : blk.mlSrc;
+            uint32_t* const cells = t == T_LL ? tLL : t == T_OF ? tOF : tML;
+            if (fail) break;
+            if (type != SET_REPEAT) {
+                if (off > blk.cSize) { fail = true; break; }
+                uint32_t const h = dev_build_from_desc(t, type, payload + off, blk.cSize - off, cells, norm, symNext, logs[t]);
+                if (h == kFail) { fail = true; break; }
+                off += h;
+            } else if (srcB == SRC_NONE) {
+                fail = true;
+            } else if (srcB == SRC_DICT) {
+                const uint32_t* const dc = t == T_LL ? p.dict->ll : t == T_OF ? p.dict->of : p.dict->ml;
+                uint32_t const lg = t == T_LL ? p.dict->llLog : t == T_OF ? p.dict->ofLog : p.dict->mlLog;
+                for (uint32_t u = 0; u < (1u << lg); u++) cells[u] = dc[u];
+                logs[t] = lg;
+            } else {
+                // rebuild from the block that defined the table: walk its descriptions up to table t
+                DevBlock const sb = p.blocks[srcB];
+                const uint8_t* const sp = p.src + sb.srcOff;
+                uint32_t o = sb.seqHdrOff;
+                for (int u = 0; u < t && !fail; u++) {
+                    uint32_t const ut = u == T_LL ? sb.llType : sb.ofType;
+                    uint32_t const sz = dev_desc_size(u, ut, sp, o, sb.cSize, norm);
+                    if (sz == kFail) fail = true; else o += sz;
+                }
+                if (!fail) {
+                    uint32_t const stype = t == T_LL ? sb.llType : t == T_OF ? sb.ofType : sb.mlType;
+                    if (o > sb.cSize || dev_build_from_desc(t, stype, sp + o, sb.cSize - o, cells, norm, symNext, logs[t]) == kFail) fail = true;
+                }
             }
         }
+        if (!fail && off >= blk.cSize) fail = true;                     // BIT_initDStream on an empty stream
+        if (!fail && payload[blk.cSize - 1] == 0) fail = true;          // no end mark
+        failU = fail ? 1u : 0u;
+        logLL = logs[T_LL]; logOF = logs[T_OF]; logML = logs[T_ML];
     }
-    BitR br;
-    if (!fail) {
-        if (off > blk.cSize || !br.init(payload + off, blk.cSize - off)) fail = true;
-    }
-    if (fail) {
-        st->seqErr = E_corruption; st->seqValid = 0; st->tailErr = 0; st->regen = blk.litSize;
-        st->repOut[0] = kSymbolicRep | (0u << kRepIdxShift); st->repOut[1] = kSymbolicRep | (1u << kRepIdxShift); st->repOut[2] = kSymbolicRep | (2u << kRepIdxShift);
+    wave_sync();
+    failU = __shfl(failU, lead);
+    off = __shfl(off, lead);
+    uint4* const out = (uint4*)p.seqBuf + blk.seqBufOff;
+    if (failU) {
+        if (leader) {
+            st->seqErr = E_corruption; st->seqValid = 0; st->tailErr = 0; st->regen = blk.litSize;
+            st->repOut[0] = kSlot0; st->repOut[1] = kSlot1; st->repOut[2] = kSlot2;
+            out[0] = make_uint4(0, 0, 0, 0);
+        }
         return;
     }
+#ifdef ZG_STAMPS
+    uint64_t const stamp1 = __builtin_readcyclecounter();
+#endif
+    const uint8_t* const sStart = payload + off;
+    uint32_t const sSize = blk.cSize - off;
+    int bitsLeft = (int)(sSize * 8) - (int)(8 - hb32(sStart[sSize - 1]));
+    uintptr_t const floorAddr = (uintptr_t)p.src;
 
-    // ZSTD_initFseState x3, order LL, OF, ML (zstd_decompress_block.pas:1266-1268)
-    uint32_t sLL = br.read(logs[T_LL]); br.refill();
-    uint32_t sOF = br.read(logs[T_OF]); br.refill();
-    uint32_t sML = br.read(logs[T_ML]); br.refill();
-
-    uint32_t r0 = kSymbolicRep | (0u << kRepIdxShift), r1 = kSymbolicRep | (1u << kRepIdxShift), r2 = kSymbolicRep | (2u << kRepIdxShift);
-    uint64_t sumML = 0;
-    uint32_t* const out = p.seqBuf + blk.seqBufOff * 3;
+    uint32_t sLL = 0, sOF = 0, sML = 0;                    // leader: FSE states
+    Rep3 rep = {kSlot0, kSlot1, kSlot2};                   // group-uniform: stack after the sequences done so far, relative to the block's incoming stack
+    uint32_t outPos = 0, litPos = 0;                       // group-uniform; saturate at 2^31-1 (frames regenerate < 2 GiB, so a saturated position always fails the capacity check)
     uint32_t const nbSeq = blk.nbSeq;
     uint32_t nValid = nbSeq;
-    for (uint32_t i = 0; i < nbSeq; i++) {
-        uint32_t const cLL = tLL[sLL], cOF = tOF[sOF], cML = tML[sML];
-        uint32_t const llCode = cLL >> 13, ofCode = cOF >> 13, mlCode = cML >> 13;
-        uint32_t const llBits = c_LL_bits[llCode], mlBits = c_ML_bits[mlCode];
-        uint32_t const llBase = c_LL_base[llCode], mlBase = c_ML_base[mlCode];
-        uint32_t offset;
-        if (ofCode > 1) {
-            uint32_t const raw = br.read(ofCode);
-            uint64_t const v = (uint64_t)((1ull << ofCode) - 3) + raw;
-            offset = v > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)v;   // anything this large is beyond every window: kept invalid
-            r2 = r1; r1 = r0; r0 = offset;
-        } else {
-            bool const ll0 = (llBase == 0);
-            if (ofCode == 0) {
-                if (!ll0) offset = r0;
-                else { offset = r1; r1 = r0; r0 = offset; }
-            } else {
-                uint32_t const code = 1 + (ll0 ? 1u : 0u) + br.read(1);
-                uint32_t const temp = code == 3 ? rep_dec1(r0) : (code == 1 ? r1 : r2);
-                if (code != 1) r2 = r1;
-                r1 = r0;
-                r0 = offset = temp;
-            }
-        }
-        uint32_t const ml = mlBase + br.read(mlBits);
-        if (llBits + mlBits + ofCode >= 31) br.refill();   // 64-bit refill rule (zstd_decompress_block.pas:1171-1174)
-        uint32_t const ll = llBase + br.read(llBits);
-        if (br.left() < 0) { nValid = i; break; }          // the extra bits of this sequence ran past the stream start
-        // state update, order LL, ML, OF (zstd_decompress_block.pas:1220-1225)
-        sLL = (cLL & 0x1FF) + br.read((cLL >> 9) & 15);
-        sML = (cML & 0x1FF) + br.read((cML >> 9) & 15);
-        sOF = (cOF & 0x1FF) + br.read((cOF >> 9) & 15);
-        out[3 * i] = ll; out[3 * i + 1] = ml; out[3 * i + 2] = offset;
-        sumML += ml;
-        if (i + 1 < nbSeq) br.refill();
+
+    // stage the top of the unread stream: 48 aligned 16-byte units, 3 per lane
+    uintptr_t wb;
+    uint4 v[3];
+    {
+        uintptr_t const top = (uintptr_t)sStart + (uintptr_t)((bitsLeft + 7) >> 3);
+        wb = ((top + 15) & ~(uintptr_t)15) - 4 * kSeqInDw;
+#pragma unroll
+        for (int k = 0; k < 3; k++) v[k] = ld_unit(wb + 16 * (gl + 16 * k), floorAddr);
     }
-    st->seqErr = 0;
-    st->seqValid = nValid;
-    // after the last sequence the reader must be at (or, through the last state update, past) the stream start (:1301)
-    st->tailErr = (nValid == nbSeq && br.left() > 0) ? (uint32_t)E_corruption : 0u;
-    st->regen = (uint64_t)blk.litSize + sumML;
-    st->repOut[0] = r0; st->repOut[1] = r1; st->repOut[2] = r2;
+    for (uint32_t base = 0; base < nbSeq; base += kSeqRound) {
+        uint32_t const n = nbSeq - base < kSeqRound ? nbSeq - base : kSeqRound;
+        lds_sync();      // the previous round's helpers have read the window
+#pragma unroll
+        for (int k = 0; k < 3; k++) *(uint4*)(inWin + 4 * (gl + 16 * k)) = v[k];
+        lds_sync();
+        int const Qbase = (int)(8 * (int64_t)((uintptr_t)sStart - wb));   // window bit index of the stream's first bit
+        // ---- leader: the serial chain
+        if (leader) {
+            uint32_t Q = (uint32_t)(Qbase + bitsLeft);   // >= 295: a round consumes < 5723 bits of a window that holds >= 6017
+            if (base == 0) {   // ZSTD_initFseState x3, order LL, OF, ML (:1266-1268), <= 26 bits
+                uint32_t tHi, tLo;
+                peek64(inWin, Q, tHi, tLo);
+                sLL = take(tHi, 0, logLL); sOF = take(tHi, logLL, logOF); sML = take(tHi, logLL + logOF, logML);
+                Q -= logLL + logOF + logML;
+            }
+#ifdef ZG_STAMPS
+            uint64_t const sl0 = __builtin_readcyclecounter();
+#endif
+            for (uint32_t i = 0; i < n; i++) {
+                uint32_t const cLL = tLL[sLL], cOF = tOF[sOF], cML = tML[sML];
+                uint32_t tHi, tLo;
+                peek64(inWin, Q, tHi, tLo);
+                uint32_t const n4 = __builtin_amdgcn_ubfe(cLL, 9, 4), n5 = __builtin_amdgcn_ubfe(cML, 9, 4), n6 = __builtin_amdgcn_ubfe(cOF, 9, 4);
+                uint32_t const nEx = __builtin_amdgcn_ubfe(cOF, 13, 5) + __builtin_amdgcn_ubfe(cML, 13, 5) + __builtin_amdgcn_ubfe(cLL, 13, 5);
+                uint32_t const nAll = nEx + n4 + n5 + n6;
+                uint32_t h3;
+                if (__builtin_expect(__any(nAll > 64), 0)) {   // long offsets with long lengths: peek again below the extra bits
+                    uint32_t uHi, uLo;
+                    peek64(inWin, Q - nEx, uHi, uLo);
+                    h3 = uHi;
+                } else h3 = shl_hi(tHi, tLo, nEx);
+                *(uint4*)(ring + 4 * i) = make_uint4(cLL, cML, cOF, Q);
+                // state update, order LL, ML, OF (:1220-1225); a cell's nextState has its low nbBits clear
+                sLL = (cLL & 0x1FF) | take(h3, 0, n4);
+                sML = (cML & 0x1FF) | take(h3, n4, n5);
+                sOF = (cOF & 0x1FF) | take(h3, n4 + n5, n6);
+                Q -= nAll;
+            }
+#ifdef ZG_STAMPS
+            stampLoop += __builtin_readcyclecounter() - sl0;
+#endif
+            bitsLeft = (int)Q - Qbase;
+        }
+        lds_sync();
+        bitsLeft = __shfl(bitsLeft, lead);
+        // ---- next round's window: issue the loads now, they land while the helpers work
+        bool const more = base + kSeqRound < nbSeq;
+        uintptr_t wbNext = wb;
+        if (more) {
+            uintptr_t const top = (uintptr_t)sStart + (uintptr_t)((bitsLeft > 0 ? bitsLeft + 7 : 0) >> 3);
+            wbNext = ((top + 15) & ~(uintptr_t)15) - 4 * kSeqInDw;
+#pragma unroll
+            for (int k = 0; k < 3; k++) v[k] = ld_unit(wbNext + 16 * (gl + 16 * k), floorAddr);
+        }
+        // ---- all lanes: sequences 4*gl .. 4*gl+3 of this round
+        uint32_t ll[4], len[4];
+        Rep3 tr[4];
+        uint32_t firstBad = kSeqRound;          // first sequence of this lane whose extra bits ran past the stream start
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            uint32_t const i = 4 * gl + u;
+            uint4 const r = *(const uint4*)(ring + 4 * i);
+            uint32_t const cLL = r.x, cML = r.y, cOF = r.z, Q = r.w;
+            uint32_t tHi, tLo;
+            peek64(inWin, i < n ? Q : 64u, tHi, tLo);
+            uint32_t const n1 = __builtin_amdgcn_ubfe(cOF, 13, 5), n2 = __builtin_amdgcn_ubfe(cML, 13, 5), n3 = __builtin_amdgcn_ubfe(cLL, 13, 5);
+            uint32_t const ofRaw = take(tHi, 0, n1);
+            uint32_t const h1 = shl_hi(tHi, tLo, n1);
+            uint32_t const llCode = (cLL >> 18) & 63, mlCode = (cML >> 18) & 63;
+            uint32_t const lli = sLLbase[llCode < 36 ? llCode : 0] + take(h1, n2, n3);
+            uint32_t const mli = sMLbase[mlCode < 53 ? mlCode : 0] + take(h1, 0, n2);
+            bool const valid = i < n;
+            if (valid && (int)(Q - (n1 + n2 + n3)) < Qbase && firstBad == kSeqRound) firstBad = i;
+            ll[u] = valid ? lli : 0;
+            len[u] = valid ? lli + mli : 0;
+            // repeat-offset step of this sequence as a stack transformation (:1105-1161):
+            //   real offset v: (v, s0, s1);  repeat idx 0: (s0, s1, s2), 1: (s1, s0, s2), 2: (s2, s0, s1), 3: (s0 - 1, s0, s1)
+            bool const isReal = n1 > 1;
+            uint32_t const real = ((1u << n1) - 3u) + ofRaw;
+            uint32_t const idx = (n1 ? 1u + ofRaw : 0u) + (llCode == 0 ? 1u : 0u);
+            Rep3 t;
+            t.a = isReal ? (real > 0x7FFFFFFFu ? 0x7FFFFFFFu : real)      // anything that large is beyond every window: kept invalid
+                         : (idx == 0 ? kSlot0 : idx == 1 ? kSlot1 : idx == 2 ? kSlot2 : (kSlot0 | 1u));
+            t.b = (isReal || idx >= 1) ? kSlot0 : kSlot1;
+            t.c = (isReal || idx >= 2) ? kSlot1 : kSlot2;
+            if (!valid) { t.a = kSlot0; t.b = kSlot1; t.c = kSlot2; }
+            tr[u] = t;
+        }
+        // lane aggregates, then an inclusive scan over the 16 lanes of the group
+        Rep3 agg = rep_compose(rep_compose(rep_compose(tr[0], tr[1]), tr[2]), tr[3]);
+        uint32_t sumLen = len[0] + len[1] + len[2] + len[3], sumLL = ll[0] + ll[1] + ll[2] + ll[3];
+        Rep3 incl = agg;
+        uint32_t inclLen = sumLen, inclLL = sumLL;
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) {
+            Rep3 o;
+            o.a = __shfl_up(incl.a, d, 16); o.b = __shfl_up(incl.b, d, 16); o.c = __shfl_up(incl.c, d, 16);
+            uint32_t const oLen = __shfl_up(inclLen, d, 16), oLL = __shfl_up(inclLL, d, 16);
+            if (gl >= (uint32_t)d) { incl = rep_compose(o, incl); inclLen += oLen; inclLL += oLL; }
+        }
+        // exclusive prefix of this lane = inclusive value of the lane before it, on top of the carry
+        Rep3 ex;
+        ex.a = __shfl_up(incl.a, 1, 16); ex.b = __shfl_up(incl.b, 1, 16); ex.c = __shfl_up(incl.c, 1, 16);
+        uint32_t exLen = __shfl_up(inclLen, 1, 16), exLL = __shfl_up(inclLL, 1, 16);
+        if (gl == 0) { ex.a = kSlot0; ex.b = kSlot1; ex.c = kSlot2; exLen = 0; exLL = 0; }
+        Rep3 cur = rep_compose(rep, ex);
+        uint32_t po = outPos + exLen, pl = litPos + exLL;     // < 2^31 + 64 * 2^18: no wrap
+        uint4 rec[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            cur = rep_compose(cur, tr[u]);
+            rec[u] = make_uint4(cur.a,   // after every sequence the top of the stack is its offset
+                                po > 0x7FFFFFFFu ? 0x7FFFFFFFu : po, pl > 0x7FFFFFFFu ? 0x7FFFFFFFu : pl, ll[u]);
+            po += len[u]; pl += ll[u];
+        }
+        // first bad sequence of the round, if any
+        uint32_t bad = firstBad;
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) { uint32_t const o = __shfl_xor(bad, d, 16); bad = o < bad ? o : bad; }
+        // records out: 64 bytes per lane, 1 KB per group, coalesced
+#pragma unroll
+        for (int u = 0; u < 4; u++) if (4 * gl + u < n) out[base + 4 * gl + u] = rec[u];
+        if (bad < n) {
+            // the stream ran dry inside this round: positions stop at the first bad sequence
+            uint32_t const src = lead + (bad >> 2), w = bad & 3;
+            uint32_t const bo = w == 0 ? rec[0].y : w == 1 ? rec[1].y : w == 2 ? rec[2].y : rec[3].y;
+            uint32_t const bl = w == 0 ? rec[0].z : w == 1 ? rec[1].z : w == 2 ? rec[2].z : rec[3].z;
+            outPos = __shfl(bo, src); litPos = __shfl(bl, src);
+            nValid = base + bad;
+            break;
+        }
+        // carry for the next round: totals of lane 15
+        {
+            uint32_t const tl = __shfl(inclLen, lead + 15), tll = __shfl(inclLL, lead + 15);
+            Rep3 tot;
+            tot.a = __shfl(incl.a, lead + 15); tot.b = __shfl(incl.b, lead + 15); tot.c = __shfl(incl.c, lead + 15);
+            rep = rep_compose(rep, tot);
+            outPos += tl; litPos += tll;
+            outPos = outPos > 0x7FFFFFFFu ? 0x7FFFFFFFu : outPos;
+            litPos = litPos > 0x7FFFFFFFu ? 0x7FFFFFFFu : litPos;
+        }
+        wb = wbNext;
+    }
+    if (leader) {
+        out[nValid] = make_uint4(0, outPos, litPos, 0);      // end record
+        st->seqErr = 0;
+        st->seqValid = nValid;
+        // after the last sequence the reader must be at (or, through the last state update, past) the stream start (:1301)
+        st->tailErr = (nValid == nbSeq && bitsLeft > 0) ? (uint32_t)E_corruption : 0u;
+        st->regen = (uint64_t)outPos + (litPos <= blk.litSize ? blk.litSize - litPos : 0);
+        st->repOut[0] = rep.a; st->repOut[1] = rep.b; st->repOut[2] = rep.c;
+#ifdef ZG_STAMPS
+        // diagnostic build: cycles spent building tables, in the decode loops, and in total, per block
+        if (p.dbg) { uint64_t const e = __builtin_readcyclecounter(); p.dbg[4 * b] = stamp1 - stamp0; p.dbg[4 * b + 1] = stampLoop; p.dbg[4 * b + 2] = e - stamp0; p.dbg[4 * b + 3] = nbSeq; }
+#endif
+    }
 }
 
 // ---------------------------------------------------------------- stage 2: per-frame layout
@@ -665,16 +965,6 @@ __global__ void k_layout(BatchParams p)
 }
 
 // ---------------------------------------------------------------- stage 3: execute
-DEVI uint32_t wave_incl_scan(uint32_t v, uint32_t lane)
-{
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t const o = __shfl_up(v, d);
-        if (lane >= (uint32_t)d) v += o;
-    }
-    return v;
-}
-
 DEVI void coop_copy(uint8_t* dst, const uint8_t* src, uint64_t n, uint32_t lane)
 {
     for (uint64_t i = lane; i < n; i += 64) dst[i] = src[i];
@@ -725,30 +1015,30 @@ __global__ __launch_bounds__(64) void k_execute(BatchParams p)
         bool const litRle = (blk.litType == SET_RLE);
         uint32_t const litSize = blk.litSize;
         uint32_t const nValid = blk.nbSeq ? st.seqValid : 0;
-        const uint32_t* const seqs = p.seqBuf + blk.seqBufOff * 3;
+        const uint32_t* const seqs = p.seqBuf + blk.seqBufOff * 4;   // nbSeq + 1 records of 4 dwords
         uint64_t pos = 0;       // bytes of this block already produced
         uint32_t litPos = 0;
 
         for (uint32_t s0 = 0; s0 < nValid && !ferr; s0 += 64) {
             uint32_t const n = nValid - s0 < 64 ? nValid - s0 : 64;
             bool const have = lane < n;
-            uint32_t ll = 0, ml = 0, off = 1;
-            if (have) {
-                ll = seqs[3 * (s0 + lane)]; ml = seqs[3 * (s0 + lane) + 1]; off = seqs[3 * (s0 + lane) + 2];
-                off = rep_resolve(off, st.repIn);
-            }
-            uint32_t const len = ll + ml;                           // <= 2 * 131074
-            uint32_t const e = wave_incl_scan(len, lane);           // 64 * 262148 < 2^32
-            uint32_t const le = wave_incl_scan(ll, lane);
-            uint32_t const start = e - len;
-            uint64_t const lstart = (uint64_t)litPos + le - ll;
+            // record i = (offset, output position, literal position) of sequence i, block-relative; record nValid is the end
+            uint32_t const ri = s0 + (have ? lane : n);
+            uint32_t off = seqs[4 * ri];
+            uint32_t const bstart = seqs[4 * ri + 1], lstart = seqs[4 * ri + 2];
+            uint32_t const rn = have ? ri + 1 : ri;
+            uint32_t const nstart = seqs[4 * rn + 1], nlit = seqs[4 * rn + 2];
+            uint32_t const ll = nlit - lstart;
+            off = have ? rep_resolve(off, st.repIn) : 1;
+            uint32_t const base0 = __shfl(bstart, 0);                // block-relative start of the batch (== pos)
+            uint32_t const start = bstart - base0;
+            uint32_t const e = nstart - base0;
             // per-sequence checks in the order of ZSTD_execSequenceEnd / ZSTD_execSequence (:896-1008)
             uint32_t code = 0;
             if (have) {
-                uint64_t const at = pos + start;                    // block-relative start of this sequence
-                if (at > room || len > room - at) code = E_dstSize_tooSmall;
-                else if (lstart > litSize || ll > litSize - lstart) code = E_corruption;
-                else if ((uint64_t)off > bo + at + ll + dictN) code = E_corruption;
+                if (nstart > room) code = E_dstSize_tooSmall;
+                else if (nlit > litSize) code = E_corruption;
+                else if ((uint64_t)off > bo + bstart + ll + dictN) code = E_corruption;
             }
             unsigned long long const bad = __ballot(code != 0);
             if (bad) { ferr = __shfl(code, __builtin_ctzll(bad)); break; }
@@ -781,7 +1071,7 @@ __global__ __launch_bounds__(64) void k_execute(BatchParams p)
                 bdst[k] = byte;
             }
             pos += total;
-            litPos += __shfl(le, 63);
+            litPos = __shfl(nlit, 63);
         }
         if (ferr) break;
         if (blk.nbSeq && nValid < blk.nbSeq) { ferr = E_corruption; break; }
@@ -902,7 +1192,7 @@ __global__ __launch_bounds__(64) void k_digest_dict(const uint8_t* dict, uint32_
         if (o > dictSize) return;
         uint32_t const h = dev_readNCount(norm, maxSV, tableLog, dict + o, dictSize - o);
         if (h == kFail || tableLog > tbl_maxLog(t)) return;
-        dev_build_seq_table(cells, norm, symNext, maxSV, tableLog);
+        dev_build_seq_table(t, cells, norm, symNext, maxSV, tableLog);
         if (t == T_LL) out->llLog = tableLog; else if (t == T_OF) out->ofLog = tableLog; else out->mlLog = tableLog;
         o += h;
     }

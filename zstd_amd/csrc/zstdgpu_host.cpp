@@ -437,7 +437,7 @@ extern "C" zstdgpu_batch* zstdgpu_batch_create(zstdgpu_ctx* ctx, const void* hos
         f.useDict = ddict ? 1 : 0;
         if (!f.hostError && fd.dictID && fd.dictID != batchDictID) f.hostError = E_dictionary_wrong;
         if (!f.hostError && (uint64_t)fd.firstBlock + fd.nBlocks > nBlocks) f.hostError = E_generic;
-        if (!f.hostError && fd.dstCapacity > 0x7FFFFFFFull) f.dstCapacity = 0x7FFFFFFFull;   // frames regenerate < 2 GiB (the port's sizes are int32)
+        if (!f.hostError && fd.dstCapacity > 0x7FFFFFFEull) f.dstCapacity = 0x7FFFFFFEull;   // frames regenerate < 2 GiB (the port's sizes are int32)
         if (f.hostError) { f.nBlocks = 0; continue; }
         B->srcBytes += fd.srcSize;
         // entropy state carried from block to block inside the frame (zstd_ddict.pas:109-126): which block defines each table
@@ -471,7 +471,7 @@ extern "C" zstdgpu_batch* zstdgpu_batch_create(zstdgpu_ctx* ctx, const void* hos
                 if (d.mlType != SET_REPEAT) mlDef = (int32_t)b;
                 d.llSrc = llDef; d.ofSrc = ofDef; d.mlSrc = mlDef;
                 d.seqBufOff = seqOff;
-                seqOff += d.nbSeq;
+                seqOff += d.nbSeq + 1;   // + the terminal record
                 B->hSeqJobs.push_back(b);
             }
         }
@@ -479,7 +479,7 @@ extern "C" zstdgpu_batch* zstdgpu_batch_create(zstdgpu_ctx* ctx, const void* hos
     B->litBytes = litOff + 64; B->nSeqTotal = seqOff;
     bool ok = dalloc(B->dBlocks, nBlocks, B->scratchBytes) && dalloc(B->dState, nBlocks, B->scratchBytes) &&
               dalloc(B->dFrames, nFrames, B->scratchBytes) && dalloc(B->dStatus, nFrames, B->scratchBytes) &&
-              dalloc(B->dLitBuf, B->litBytes, B->scratchBytes) && dalloc(B->dSeqBuf, seqOff * 3 + 4, B->scratchBytes) &&
+              dalloc(B->dLitBuf, B->litBytes, B->scratchBytes) && dalloc(B->dSeqBuf, seqOff * 4 + 4, B->scratchBytes) &&
               dalloc(B->dLitJobs, B->hLitJobs.size(), B->scratchBytes) && dalloc(B->dSeqJobs, B->hSeqJobs.size(), B->scratchBytes);
     auto up = [&](void* d, const void* h, size_t n) { return n == 0 || hipMemcpy(d, h, n, hipMemcpyHostToDevice) == hipSuccess; };
     ok = ok && up(B->dBlocks, B->hBlocks.data(), nBlocks * sizeof(DevBlock)) && up(B->dFrames, B->hFrames.data(), nFrames * sizeof(DevFrame)) &&
@@ -523,6 +523,12 @@ extern "C" size_t zstdgpu_batch_decode(zstdgpu_batch* B, const void* devSrc, voi
         p.dictContent = B->ddict->dBytes + B->ddict->entropySize;
         p.dictContentSize = B->ddict->size - B->ddict->entropySize;
     }
+#ifdef ZG_STAMPS
+    static uint64_t* dbgBuf = nullptr; static size_t dbgCap = 0;
+    if (dbgCap < p.nBlocks) { hipFree(dbgBuf); hipMalloc((void**)&dbgBuf, (size_t)p.nBlocks * 32); dbgCap = p.nBlocks; }
+    hipMemsetAsync(dbgBuf, 0, (size_t)p.nBlocks * 32, s);
+    p.dbg = dbgBuf;
+#endif
     bool const prof = B->profiling && B->evReady;
     if (prof) hipEventRecord(B->ev[0], s);
     if (p.nBlocks) hipMemsetAsync(B->dState, 0, (size_t)p.nBlocks * sizeof(DevBlockState), s);
@@ -537,6 +543,17 @@ extern "C" size_t zstdgpu_batch_decode(zstdgpu_batch* B, const void* devSrc, voi
     launch_checksum(p, s);
     if (prof) { hipEventRecord(B->ev[5], s); B->evRecorded = true; }
     B->lastStream = s;
+#ifdef ZG_STAMPS
+    {   // diagnostic build: print where the sequence stage spends its cycles
+        hipStreamSynchronize(s);
+        std::vector<uint64_t> h((size_t)p.nBlocks * 4);
+        hipMemcpy(h.data(), dbgBuf, h.size() * 8, hipMemcpyDeviceToHost);
+        double tb = 0, lp = 0, tot = 0, ns = 0; uint64_t mx = 0; size_t n = 0;
+        for (size_t i = 0; i < p.nBlocks; i++) if (h[4 * i + 2]) { tb += h[4 * i]; lp += h[4 * i + 1]; tot += h[4 * i + 2]; ns += h[4 * i + 3]; if (h[4 * i + 2] > mx) mx = h[4 * i + 2]; n++; }
+        if (n) fprintf(stderr, "[stamps] k_sequences per block: tables %.0f  decode loops %.0f  total %.0f (max %llu) ticks; %.0f seqs; %.1f loop ticks/seq\n",
+                       tb / n, lp / n, tot / n, (unsigned long long)mx, ns / n, lp / ns);
+    }
+#endif
     return hipGetLastError() == hipSuccess ? 0 : mkerr(E_generic);
 }
 
@@ -643,13 +660,19 @@ extern "C" size_t zstdgpu_batch_copySequences(zstdgpu_batch* B, uint32_t bi, uin
     if (!d.nbSeq) return 0;
     DevBlockState st;
     if (hipMemcpy(&st, B->dState + bi, sizeof(st), hipMemcpyDeviceToHost) != hipSuccess) return mkerr(E_generic);
-    if (hipMemcpy(triples, B->dSeqBuf + d.seqBufOff * 3, (size_t)d.nbSeq * 12, hipMemcpyDeviceToHost) != hipSuccess) return mkerr(E_generic);
-    for (uint32_t i = 0; i < d.nbSeq; i++) {   // offsets that referred to the incoming rep stack become concrete here
-        uint32_t const x = triples[3 * i + 2];
-        if (x & kSymbolicRep) {
+    std::vector<uint32_t> rec(((size_t)d.nbSeq + 1) * 4);
+    if (hipMemcpy(rec.data(), B->dSeqBuf + d.seqBufOff * 4, rec.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return mkerr(E_generic);
+    // device records are (offset, output position, literal position); lengths are differences of neighbours
+    for (uint32_t i = 0; i < st.seqValid; i++) {
+        uint32_t x = rec[4 * i];
+        if (x & kSymbolicRep) {   // offsets that referred to the incoming rep stack become concrete here
             uint32_t const v = st.repIn[(x >> 29) & 3], dl = x & ((1u << 29) - 1);
-            triples[3 * i + 2] = v > dl ? v - dl : 1;
+            x = v > dl ? v - dl : 1;
         }
+        uint32_t const ll = rec[4 * i + 3];
+        triples[3 * i] = ll;
+        triples[3 * i + 1] = rec[4 * (i + 1) + 1] - rec[4 * i + 1] - ll;
+        triples[3 * i + 2] = x;
     }
     return st.seqValid;
 }
@@ -673,7 +696,7 @@ size_t decompress_multi(zstdgpu_ctx* ctx, void* dst, size_t dstCapacity, const v
     if (!ctx || !set_device(ctx)) return mkerr(E_generic);
     if (ddict && ddict->status) return mkerr(ddict->status);
     const uint8_t* const src = (const uint8_t*)srcv;
-    if (srcSize > 0x7FFFFFFFu || dstCapacity > 0x7FFFFFFFu) { if (srcSize > 0x7FFFFFFFu) return mkerr(E_srcSize_wrong); dstCapacity = 0x7FFFFFFFu; }
+    if (srcSize > 0x7FFFFFFFu || dstCapacity > 0x7FFFFFFEu) { if (srcSize > 0x7FFFFFFFu) return mkerr(E_srcSize_wrong); dstCapacity = 0x7FFFFFFEu; }
     // split into frames on the host
     std::vector<zstdgpu_frame_in> ins;
     std::vector<uint64_t> known;      // content size of each frame or UNKNOWN

@@ -99,6 +99,9 @@ struct BatchParams {
     const uint8_t* dictContent;  // device pointer to dictionary content
     uint32_t dictContentSize;
     uint32_t nLitJobs, nSeqJobs, nFrames, nBlocks;
+#ifdef ZG_STAMPS
+    uint64_t* dbg;               // diagnostic build only: 4 cycle counters per block
+#endif
 };
 
 // kernel launchers (kernels.hip)
