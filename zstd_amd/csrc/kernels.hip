@@ -970,6 +970,54 @@ DEVI void coop_copy(uint8_t* dst, const uint8_t* src, uint64_t n, uint32_t lane)
     for (uint64_t i = lane; i < n; i += 64) dst[i] = src[i];
 }
 
+// Context of one batch of <= 64 sequences for byte resolution.  Positions are relative to the first
+// output byte of the batch; sStart/sLL/sOff/sLit describe the batch's sequences in LDS.
+struct ExecCtx {
+    const uint32_t *sStart, *sLL, *sOff, *sLit;
+    const uint8_t* litBase;
+    const uint8_t* fdst;        // frame output
+    const uint8_t* dictEnd;     // one past the dictionary content
+    int64_t batchAbs;           // frame-relative position of batch byte 0
+    uint32_t n;
+    bool litRle;
+};
+
+// Where the byte that ends up at batch position k comes from.  A position before the batch is already
+// in memory (frame output, or dictionary when it reaches before the frame).  A position inside the
+// batch is either a literal, or a match byte whose own source is followed in turn -- each hop lands
+// in an earlier sequence, so the walk ends; overlapping matches (offset < matchLength) fold with a
+// modulo.  This replaces the byte-serial ZSTD_overlapCopy8 / ZSTD_safecopy
+// (zstd_decompress_block.pas:793-885).  Wave-uniform loop: one trip unless some lane's match reads
+// bytes produced inside this batch.
+DEVI const uint8_t* resolve_source(const ExecCtx& c, uint32_t k, bool active)
+{
+    const uint8_t* ptr = c.litBase;
+    int32_t q = (int32_t)k;
+    bool pending = active;
+    for (int hop = 0; hop < 66 && __any(pending); hop++) {
+        // owner = last sequence whose start <= q; sStart is padded to 64 entries with the batch size
+        uint32_t lo = 0;
+#pragma unroll
+        for (int step = 32; step >= 1; step >>= 1) { uint32_t const mid = lo + step; lo = (c.sStart[mid] <= (uint32_t)q) ? mid : lo; }
+        uint32_t const r = (uint32_t)q - c.sStart[lo], sll = c.sLL[lo];
+        const uint8_t* cand;
+        bool resolved;
+        if (r < sll) { cand = c.litRle ? c.litBase : c.litBase + c.sLit[lo] + r; resolved = true; }
+        else {
+            uint32_t m = r - sll;
+            uint32_t const so = c.sOff[lo];
+            if (m >= so) m %= so;                       // overlapping match: the pattern of `so` bytes repeats
+            int32_t const nq = (int32_t)(c.sStart[lo] + sll + m) - (int32_t)so;   // so <= 2^31-1 and positions < 2^31: no wrap
+            int64_t const abs = c.batchAbs + nq;
+            cand = abs >= 0 ? c.fdst + abs : c.dictEnd + abs;
+            resolved = nq < 0;
+            if (pending && !resolved) q = nq;
+        }
+        if (pending && resolved) { ptr = cand; pending = false; }
+    }
+    return ptr;
+}
+
 __global__ __launch_bounds__(64) void k_execute(BatchParams p)
 {
     __shared__ uint32_t sStart[65], sLL[64], sOff[64], sLit[64];
@@ -1015,63 +1063,51 @@ __global__ __launch_bounds__(64) void k_execute(BatchParams p)
         bool const litRle = (blk.litType == SET_RLE);
         uint32_t const litSize = blk.litSize;
         uint32_t const nValid = blk.nbSeq ? st.seqValid : 0;
-        const uint32_t* const seqs = p.seqBuf + blk.seqBufOff * 4;   // nbSeq + 1 records of 4 dwords
+        const uint4* const recs = (const uint4*)p.seqBuf + blk.seqBufOff;   // nbSeq + 1 records
+        uint32_t const rin0 = st.repIn[0], rin1 = st.repIn[1], rin2 = st.repIn[2];
         uint64_t pos = 0;       // bytes of this block already produced
         uint32_t litPos = 0;
 
         for (uint32_t s0 = 0; s0 < nValid && !ferr; s0 += 64) {
             uint32_t const n = nValid - s0 < 64 ? nValid - s0 : 64;
             bool const have = lane < n;
-            // record i = (offset, output position, literal position) of sequence i, block-relative; record nValid is the end
+            // one sequence per lane: record = (offset, output position, literal position, litLength), block-relative
             uint32_t const ri = s0 + (have ? lane : n);
-            uint32_t off = seqs[4 * ri];
-            uint32_t const bstart = seqs[4 * ri + 1], lstart = seqs[4 * ri + 2];
-            uint32_t const rn = have ? ri + 1 : ri;
-            uint32_t const nstart = seqs[4 * rn + 1], nlit = seqs[4 * rn + 2];
-            uint32_t const ll = nlit - lstart;
-            off = have ? rep_resolve(off, st.repIn) : 1;
-            uint32_t const base0 = __shfl(bstart, 0);                // block-relative start of the batch (== pos)
-            uint32_t const start = bstart - base0;
-            uint32_t const e = nstart - base0;
+            uint4 const rc = recs[ri];
+            uint32_t const nstart = have ? recs[ri + 1].y : rc.y;
+            uint32_t const bstart = rc.y, lstart = rc.z;
+            uint32_t const ll = have ? rc.w : 0;
+            uint32_t const off = have ? rep_subst(rc.x, rin0, rin1, rin2) : 1;
             // per-sequence checks in the order of ZSTD_execSequenceEnd / ZSTD_execSequence (:896-1008)
             uint32_t code = 0;
             if (have) {
                 if (nstart > room) code = E_dstSize_tooSmall;
-                else if (nlit > litSize) code = E_corruption;
+                else if ((uint64_t)lstart + ll > litSize) code = E_corruption;
                 else if ((uint64_t)off > bo + bstart + ll + dictN) code = E_corruption;
             }
             unsigned long long const bad = __ballot(code != 0);
             if (bad) { ferr = __shfl(code, __builtin_ctzll(bad)); break; }
-            wave_sync();      // earlier batches' stores are complete and visible; previous LDS reads done
-            sStart[lane] = start; sLL[lane] = ll; sOff[lane] = off; sLit[lane] = (uint32_t)lstart;
-            if (lane == 63) sStart[64] = e;
-            wave_sync();
-            uint32_t const total = __shfl(e, 63);
+            uint32_t const base0 = __shfl(bstart, 0);                // block-relative start of the batch (== pos)
+            uint32_t const start = bstart - base0;
+            uint32_t const total = __shfl(nstart, 63) - base0;
+            wave_sync();      // earlier stores are complete and visible; previous LDS reads done
+            sStart[lane] = start; sLL[lane] = ll; sOff[lane] = off; sLit[lane] = lstart;
+            if (lane == 63) sStart[64] = total;
+            lds_sync();
+            ExecCtx c;
+            c.sStart = sStart; c.sLL = sLL; c.sOff = sOff; c.sLit = sLit;
+            c.litBase = litBase; c.fdst = fdst; c.dictEnd = dictEnd;
+            c.batchAbs = (int64_t)(bo + pos); c.n = n; c.litRle = litRle;
+            // every lane produces bytes lane, lane+64, ... of the batch (coalesced loads and stores)
             uint8_t* const bdst = fdst + bo + pos;
-            int64_t const batchAbs = (int64_t)(bo + pos);           // frame-relative position of batch byte 0
-            for (uint32_t k = lane; k < total; k += 64) {
-                uint32_t q = k;
-                uint8_t byte = 0;
-                for (int hop = 0; hop < 65; hop++) {
-                    // sequence owning batch byte q: last s with sStart[s] <= q
-                    uint32_t lo = 0, hi = n - 1;
-                    while (lo < hi) { uint32_t const mid = (lo + hi + 1) >> 1; if (sStart[mid] <= q) lo = mid; else hi = mid - 1; }
-                    uint32_t const r = q - sStart[lo];
-                    uint32_t const sll = sLL[lo];
-                    if (r < sll) { byte = litRle ? litBase[0] : litBase[sLit[lo] + r]; break; }
-                    uint32_t const m = r - sll, so = sOff[lo];
-                    int64_t const src = (int64_t)(sStart[lo] + sll) - (int64_t)so + (int64_t)(m < so ? m : m % so);
-                    if (src < 0) {
-                        int64_t const abs = batchAbs + src;
-                        byte = abs >= 0 ? fdst[abs] : dictEnd[abs];
-                        break;
-                    }
-                    q = (uint32_t)src;
-                }
-                bdst[k] = byte;
+            for (uint32_t k0 = 0; k0 < total; k0 += 64) {
+                uint32_t const k = k0 + lane;
+                bool const act = k < total;
+                const uint8_t* const sp = resolve_source(c, act ? k : 0, act);
+                if (act) bdst[k] = *sp;
             }
             pos += total;
-            litPos = __shfl(nlit, 63);
+            litPos = __shfl(lstart + ll, 63);
         }
         if (ferr) break;
         if (blk.nbSeq && nValid < blk.nbSeq) { ferr = E_corruption; break; }
