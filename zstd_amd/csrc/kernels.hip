@@ -971,58 +971,78 @@ DEVI void coop_copy(uint8_t* dst, const uint8_t* src, uint64_t n, uint32_t lane)
 }
 
 // Context of one batch of <= 64 sequences for byte resolution.  Positions are relative to the first
-// output byte of the batch; sStart/sLL/sOff/sLit describe the batch's sequences in LDS.
+// output byte of the batch; sStart/sLL/sOff/sLit describe the batch's sequences in LDS (sStart padded
+// to 64 entries with the batch size).  ownerArr[q] = sequence that produces batch byte q, filled pass
+// by pass for batches of at most kOwnerCap bytes; larger batches search sStart instead.
+constexpr uint32_t kOwnerCap = 2048;
 struct ExecCtx {
     const uint32_t *sStart, *sLL, *sOff, *sLit;
+    const uint8_t* ownerArr;
+    const uint8_t* outStage;    // small batches: the batch bytes produced by earlier passes
     const uint8_t* litBase;
     const uint8_t* fdst;        // frame output
     const uint8_t* dictEnd;     // one past the dictionary content
     int64_t batchAbs;           // frame-relative position of batch byte 0
-    uint32_t n;
-    bool litRle;
+    bool litRle, small;
 };
 
-// Where the byte that ends up at batch position k comes from.  A position before the batch is already
-// in memory (frame output, or dictionary when it reaches before the frame).  A position inside the
-// batch is either a literal, or a match byte whose own source is followed in turn -- each hop lands
-// in an earlier sequence, so the walk ends; overlapping matches (offset < matchLength) fold with a
-// modulo.  This replaces the byte-serial ZSTD_overlapCopy8 / ZSTD_safecopy
-// (zstd_decompress_block.pas:793-885).  Wave-uniform loop: one trip unless some lane's match reads
-// bytes produced inside this batch.
-DEVI const uint8_t* resolve_source(const ExecCtx& c, uint32_t k, bool active)
+DEVI uint32_t owner_of(const ExecCtx& c, uint32_t q)
 {
-    const uint8_t* ptr = c.litBase;
-    int32_t q = (int32_t)k;
+    if (c.small) return c.ownerArr[q];
+    uint32_t lo = 0;
+#pragma unroll
+    for (int step = 32; step >= 1; step >>= 1) { uint32_t const mid = lo + step; lo = (c.sStart[mid] <= q) ? mid : lo; }
+    return lo;
+}
+
+// Where the byte that ends up at batch position k comes from; `own` is the sequence producing k.
+// A position before the batch is already in memory (frame output, or dictionary when it reaches
+// before the frame).  A position inside the batch is either a literal, or a match byte whose own
+// source is followed in turn -- each hop lands in an earlier sequence, so the walk ends; overlapping
+// matches (offset < matchLength) fold with a modulo.  This replaces the byte-serial
+// ZSTD_overlapCopy8 / ZSTD_safecopy (zstd_decompress_block.pas:793-885).  Wave-uniform loop: one
+// trip unless some lane's match reads bytes produced inside this batch.
+// Returns the byte.  `k0` is the first byte of the current pass: in a small batch every byte below k0
+// is already in the LDS stage.
+DEVI uint8_t resolve_byte(const ExecCtx& c, uint32_t k, uint32_t k0, uint32_t own, bool active)
+{
+    const uint8_t* gptr = c.litBase;     // global source ...
+    uint32_t lpos = 0;                   // ... or position in the LDS stage
+    bool fromStage = false;
+    uint32_t q = k;
     bool pending = active;
     for (int hop = 0; hop < 66 && __any(pending); hop++) {
-        // owner = last sequence whose start <= q; sStart is padded to 64 entries with the batch size
-        uint32_t lo = 0;
-#pragma unroll
-        for (int step = 32; step >= 1; step >>= 1) { uint32_t const mid = lo + step; lo = (c.sStart[mid] <= (uint32_t)q) ? mid : lo; }
-        uint32_t const r = (uint32_t)q - c.sStart[lo], sll = c.sLL[lo];
+        uint32_t const st = c.sStart[own];
+        uint32_t const r = q - st, sll = c.sLL[own];
         const uint8_t* cand;
-        bool resolved;
-        if (r < sll) { cand = c.litRle ? c.litBase : c.litBase + c.sLit[lo] + r; resolved = true; }
+        bool resolved, stage = false;
+        if (r < sll) { cand = c.litRle ? c.litBase : c.litBase + c.sLit[own] + r; resolved = true; }
         else {
             uint32_t m = r - sll;
-            uint32_t const so = c.sOff[lo];
+            uint32_t const so = c.sOff[own];
             if (m >= so) m %= so;                       // overlapping match: the pattern of `so` bytes repeats
-            int32_t const nq = (int32_t)(c.sStart[lo] + sll + m) - (int32_t)so;   // so <= 2^31-1 and positions < 2^31: no wrap
+            int32_t const nq = (int32_t)(st + sll + m) - (int32_t)so;   // so <= 2^31-1 and positions < 2^31: no wrap
             int64_t const abs = c.batchAbs + nq;
             cand = abs >= 0 ? c.fdst + abs : c.dictEnd + abs;
-            resolved = nq < 0;
-            if (pending && !resolved) q = nq;
+            stage = c.small && nq >= 0 && (uint32_t)nq < k0;
+            resolved = nq < 0 || stage;
+            if (pending && !resolved) { q = (uint32_t)nq; own = owner_of(c, q); }
+            if (pending && stage) lpos = (uint32_t)nq;
         }
-        if (pending && resolved) { ptr = cand; pending = false; }
+        if (pending && resolved) { gptr = cand; fromStage = stage; pending = false; }
     }
-    return ptr;
+    uint8_t v = 0;
+    if (active) v = fromStage ? c.outStage[lpos] : *gptr;
+    return v;
 }
 
 __global__ __launch_bounds__(64) void k_execute(BatchParams p)
 {
     __shared__ uint32_t sStart[65], sLL[64], sOff[64], sLit[64];
+    __shared__ __attribute__((aligned(16))) uint8_t startFlag[kOwnerCap + 64], ownerArr[kOwnerCap + 64], outStage[kOwnerCap + 64];
     uint32_t const lane = threadIdx.x;
     uint32_t const fi = blockIdx.x;
+    for (uint32_t i = lane; i < (kOwnerCap + 64) / 4; i += 64) ((uint32_t*)startFlag)[i] = 0;
     DevFrame const f = p.frames[fi];
     DevFrameStatus* const fs = p.status + fi;
     if (fs->errorCode) return;   // host error or unusable dictionary (set by k_layout)
@@ -1094,18 +1114,32 @@ __global__ __launch_bounds__(64) void k_execute(BatchParams p)
             sStart[lane] = start; sLL[lane] = ll; sOff[lane] = off; sLit[lane] = lstart;
             if (lane == 63) sStart[64] = total;
             lds_sync();
+            bool const small = total <= kOwnerCap;
+            if (small && have) startFlag[start] = 1;       // sequence starts are distinct: every real sequence is >= 3 bytes
+            lds_sync();
             ExecCtx c;
-            c.sStart = sStart; c.sLL = sLL; c.sOff = sOff; c.sLit = sLit;
+            c.sStart = sStart; c.sLL = sLL; c.sOff = sOff; c.sLit = sLit; c.ownerArr = ownerArr; c.outStage = outStage;
             c.litBase = litBase; c.fdst = fdst; c.dictEnd = dictEnd;
-            c.batchAbs = (int64_t)(bo + pos); c.n = n; c.litRle = litRle;
+            c.batchAbs = (int64_t)(bo + pos); c.litRle = litRle; c.small = small;
             // every lane produces bytes lane, lane+64, ... of the batch (coalesced loads and stores)
             uint8_t* const bdst = fdst + bo + pos;
+            uint32_t before = 0;                            // sequences that start before this pass
             for (uint32_t k0 = 0; k0 < total; k0 += 64) {
                 uint32_t const k = k0 + lane;
                 bool const act = k < total;
-                const uint8_t* const sp = resolve_source(c, act ? k : 0, act);
-                if (act) bdst[k] = *sp;
+                uint32_t own;
+                if (small) {
+                    // owner = (number of sequence starts <= k) - 1, counted with a ballot over the start flags
+                    bool const f = act && startFlag[k] != 0;
+                    unsigned long long const m = __ballot(f);
+                    own = before + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0)) + (f ? 1u : 0u) - 1u;
+                    before += (uint32_t)__builtin_popcountll(m);
+                    if (act) ownerArr[k] = (uint8_t)own;
+                } else own = owner_of(c, act ? k : 0);
+                uint8_t const v = resolve_byte(c, act ? k : 0, k0, act ? own : 0, act);
+                if (act) { bdst[k] = v; if (small) outStage[k] = v; }
             }
+            if (small && have) startFlag[start] = 0;
             pos += total;
             litPos = __shfl(lstart + ll, 63);
         }
