@@ -972,23 +972,19 @@ DEVI void coop_copy(uint8_t* dst, const uint8_t* src, uint64_t n, uint32_t lane)
 
 // Context of one batch of <= 64 sequences for byte resolution.  Positions are relative to the first
 // output byte of the batch; sStart/sLL/sOff/sLit describe the batch's sequences in LDS (sStart padded
-// to 64 entries with the batch size).  ownerArr[q] = sequence that produces batch byte q, filled pass
-// by pass for batches of at most kOwnerCap bytes; larger batches search sStart instead.
-constexpr uint32_t kOwnerCap = 2048;
+// to 65 entries with the batch size).
 struct ExecCtx {
     const uint32_t *sStart, *sLL, *sOff, *sLit;
-    const uint8_t* ownerArr;
-    const uint8_t* outStage;    // small batches: the batch bytes produced by earlier passes
     const uint8_t* litBase;
     const uint8_t* fdst;        // frame output
     const uint8_t* dictEnd;     // one past the dictionary content
     int64_t batchAbs;           // frame-relative position of batch byte 0
-    bool litRle, small;
+    bool litRle;
 };
 
+// last sequence whose start <= q
 DEVI uint32_t owner_of(const ExecCtx& c, uint32_t q)
 {
-    if (c.small) return c.ownerArr[q];
     uint32_t lo = 0;
 #pragma unroll
     for (int step = 32; step >= 1; step >>= 1) { uint32_t const mid = lo + step; lo = (c.sStart[mid] <= q) ? mid : lo; }
@@ -1000,22 +996,17 @@ DEVI uint32_t owner_of(const ExecCtx& c, uint32_t q)
 // before the frame).  A position inside the batch is either a literal, or a match byte whose own
 // source is followed in turn -- each hop lands in an earlier sequence, so the walk ends; overlapping
 // matches (offset < matchLength) fold with a modulo.  This replaces the byte-serial
-// ZSTD_overlapCopy8 / ZSTD_safecopy (zstd_decompress_block.pas:793-885).  Wave-uniform loop: one
-// trip unless some lane's match reads bytes produced inside this batch.
-// Returns the byte.  `k0` is the first byte of the current pass: in a small batch every byte below k0
-// is already in the LDS stage.
-DEVI uint8_t resolve_byte(const ExecCtx& c, uint32_t k, uint32_t k0, uint32_t own, bool active)
+// ZSTD_overlapCopy8 / ZSTD_safecopy (zstd_decompress_block.pas:793-885).  Wave-uniform loop.
+DEVI const uint8_t* resolve_source(const ExecCtx& c, uint32_t k, uint32_t own, bool active)
 {
-    const uint8_t* gptr = c.litBase;     // global source ...
-    uint32_t lpos = 0;                   // ... or position in the LDS stage
-    bool fromStage = false;
+    const uint8_t* ptr = c.litBase;
     uint32_t q = k;
     bool pending = active;
     for (int hop = 0; hop < 66 && __any(pending); hop++) {
         uint32_t const st = c.sStart[own];
         uint32_t const r = q - st, sll = c.sLL[own];
         const uint8_t* cand;
-        bool resolved, stage = false;
+        bool resolved;
         if (r < sll) { cand = c.litRle ? c.litBase : c.litBase + c.sLit[own] + r; resolved = true; }
         else {
             uint32_t m = r - sll;
@@ -1024,25 +1015,80 @@ DEVI uint8_t resolve_byte(const ExecCtx& c, uint32_t k, uint32_t k0, uint32_t ow
             int32_t const nq = (int32_t)(st + sll + m) - (int32_t)so;   // so <= 2^31-1 and positions < 2^31: no wrap
             int64_t const abs = c.batchAbs + nq;
             cand = abs >= 0 ? c.fdst + abs : c.dictEnd + abs;
-            stage = c.small && nq >= 0 && (uint32_t)nq < k0;
-            resolved = nq < 0 || stage;
+            resolved = nq < 0;
             if (pending && !resolved) { q = (uint32_t)nq; own = owner_of(c, q); }
-            if (pending && stage) lpos = (uint32_t)nq;
         }
-        if (pending && resolved) { gptr = cand; fromStage = stage; pending = false; }
+        if (pending && resolved) { ptr = cand; pending = false; }
     }
-    uint8_t v = 0;
-    if (active) v = fromStage ? c.outStage[lpos] : *gptr;
-    return v;
+    return ptr;
 }
 
-__global__ __launch_bounds__(64) void k_execute(BatchParams p)
+// One run (a sequence's literals, or a match whose source lies wholly before the batch and does not
+// overlap its destination) copied by one lane with exact-size unaligned accesses: up to two 16-byte
+// chunks and the 8/4/2/1-byte pieces of the remainder.  load() issues every load of the run, store()
+// every store, so a wave can issue all loads of a batch before its first store (a wave's loads and
+// stores retire in issue order).  Runs of 48 bytes or more keep `more` 16-byte chunks for a
+// cooperative loop.
+struct Run {
+    uint4 a, b;
+    uint2 c8;
+    uint32_t c4;
+    uint16_t c2;
+    uint8_t c1;
+    DEVI void load(const uint8_t* src, uint32_t len, bool splat)
+    {
+        uint32_t const n16 = len >> 4;
+        if (splat) {     // RLE literals: every byte is src[0]
+            uint32_t const v = 0x01010101u * src[0];
+            a = b = make_uint4(v, v, v, v); c8 = make_uint2(v, v); c4 = v; c2 = (uint16_t)v; c1 = (uint8_t)v;
+            return;
+        }
+        if (n16 >= 1) __builtin_memcpy(&a, src, 16);
+        if (n16 >= 2) __builtin_memcpy(&b, src + 16, 16);
+        uint32_t po = n16 << 4;
+        if (len & 8) { __builtin_memcpy(&c8, src + po, 8); po += 8; }
+        if (len & 4) { __builtin_memcpy(&c4, src + po, 4); po += 4; }
+        if (len & 2) { __builtin_memcpy(&c2, src + po, 2); po += 2; }
+        if (len & 1) c1 = src[po];
+    }
+    DEVI void store(uint8_t* dst, uint32_t len) const
+    {
+        uint32_t const n16 = len >> 4;
+        if (n16 >= 1) __builtin_memcpy(dst, &a, 16);
+        if (n16 >= 2) __builtin_memcpy(dst + 16, &b, 16);
+        uint32_t po = n16 << 4;
+        if (len & 8) { __builtin_memcpy(dst + po, &c8, 8); po += 8; }
+        if (len & 4) { __builtin_memcpy(dst + po, &c4, 4); po += 4; }
+        if (len & 2) { __builtin_memcpy(dst + po, &c2, 2); po += 2; }
+        if (len & 1) dst[po] = c1;
+    }
+};
+
+// chunks 2 .. n16-1 of every run longer than 47 bytes, copied by the whole wave (16 bytes per lane)
+DEVI void copy_long_runs(uint8_t* dst, const uint8_t* src, uint32_t len, bool splat, uint32_t lane)
 {
-    __shared__ uint32_t sStart[65], sLL[64], sOff[64], sLit[64];
-    __shared__ __attribute__((aligned(16))) uint8_t startFlag[kOwnerCap + 64], ownerArr[kOwnerCap + 64], outStage[kOwnerCap + 64];
+    unsigned long long longs = __ballot((len >> 4) > 2);
+    while (longs) {
+        uint32_t const who = (uint32_t)__builtin_ctzll(longs);
+        longs &= longs - 1;
+        uint32_t const n16 = __shfl(len, who) >> 4;
+        uint8_t* const d = (uint8_t*)(uintptr_t)__shfl((unsigned long long)(uintptr_t)dst, who);
+        const uint8_t* const sp = (const uint8_t*)(uintptr_t)__shfl((unsigned long long)(uintptr_t)src, who);
+        bool const sv = __shfl((int)splat, who) != 0;
+        uint32_t const v = sv ? 0x01010101u * sp[0] : 0;
+        for (uint32_t i = 2 + lane; i < n16; i += 64) {
+            uint4 x = make_uint4(v, v, v, v);
+            if (!sv) __builtin_memcpy(&x, sp + 16 * (size_t)i, 16);
+            __builtin_memcpy(d + 16 * (size_t)i, &x, 16);
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_execute(BatchParams p)
+{
+    __shared__ uint32_t sStart[65], sLL[64], sOff[64], sLit[64], sSlowEnd[64];
     uint32_t const lane = threadIdx.x;
     uint32_t const fi = blockIdx.x;
-    for (uint32_t i = lane; i < (kOwnerCap + 64) / 4; i += 64) ((uint32_t*)startFlag)[i] = 0;
     DevFrame const f = p.frames[fi];
     DevFrameStatus* const fs = p.status + fi;
     if (fs->errorCode) return;   // host error or unusable dictionary (set by k_layout)
@@ -1088,13 +1134,22 @@ __global__ __launch_bounds__(64) void k_execute(BatchParams p)
         uint64_t pos = 0;       // bytes of this block already produced
         uint32_t litPos = 0;
 
+        // One sequence per lane: record = (offset, output position, literal position, litLength), block-relative;
+        // lanes past the batch's last sequence read the record after it, whose output position ends the batch.
+        // The records of the next batch are requested before the stores of the current one.
+        uint4 rcN = make_uint4(0, 0, 0, 0);
+        uint32_t endN = 0;
+        if (nValid) {
+            uint32_t const n = nValid < 64 ? nValid : 64;
+            rcN = recs[lane < n ? lane : n];
+            endN = recs[n].y;
+        }
         for (uint32_t s0 = 0; s0 < nValid && !ferr; s0 += 64) {
             uint32_t const n = nValid - s0 < 64 ? nValid - s0 : 64;
             bool const have = lane < n;
-            // one sequence per lane: record = (offset, output position, literal position, litLength), block-relative
-            uint32_t const ri = s0 + (have ? lane : n);
-            uint4 const rc = recs[ri];
-            uint32_t const nstart = have ? recs[ri + 1].y : rc.y;
+            uint4 const rc = rcN;
+            uint32_t const below = __shfl_down(rc.y, 1);
+            uint32_t const nstart = lane == 63 ? endN : (have ? below : rc.y);
             uint32_t const bstart = rc.y, lstart = rc.z;
             uint32_t const ll = have ? rc.w : 0;
             uint32_t const off = have ? rep_subst(rc.x, rin0, rin1, rin2) : 1;
@@ -1107,39 +1162,79 @@ __global__ __launch_bounds__(64) void k_execute(BatchParams p)
             }
             unsigned long long const bad = __ballot(code != 0);
             if (bad) { ferr = __shfl(code, __builtin_ctzll(bad)); break; }
+            uint32_t const ml = nstart - bstart - ll;
             uint32_t const base0 = __shfl(bstart, 0);                // block-relative start of the batch (== pos)
             uint32_t const start = bstart - base0;
             uint32_t const total = __shfl(nstart, 63) - base0;
+            int64_t const batchAbs = (int64_t)(bo + pos);
+            // A match is "fast" when its source lies wholly before the batch, on one side of the dictionary
+            // boundary, and does not overlap its destination: a plain copy.  Everything else (about 1 match in
+            // 12 on text) is resolved byte by byte below.
+            int32_t const ms = (int32_t)(start + ll) - (int32_t)off;           // batch-relative source start
+            int64_t const absS = batchAbs + ms;
+            bool const fast = have && off >= ml && ms + (int32_t)ml <= 0 && (absS >= 0 || absS + (int64_t)ml <= 0);
+            uint32_t const fastLen = fast ? ml : 0, slowLen = (have && !fast) ? ml : 0;
+            // inclusive prefix of the slow match bytes over the lanes
+            uint32_t slowEnd = slowLen;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { uint32_t const o = __shfl_up(slowEnd, d); if (lane >= (uint32_t)d) slowEnd += o; }
+            uint32_t const slowTotal = __shfl(slowEnd, 63);
+
             wave_sync();      // earlier stores are complete and visible; previous LDS reads done
-            sStart[lane] = start; sLL[lane] = ll; sOff[lane] = off; sLit[lane] = lstart;
+            sStart[lane] = start; sLL[lane] = ll; sOff[lane] = off; sLit[lane] = lstart; sSlowEnd[lane] = slowEnd;
             if (lane == 63) sStart[64] = total;
             lds_sync();
-            bool const small = total <= kOwnerCap;
-            if (small && have) startFlag[start] = 1;       // sequence starts are distinct: every real sequence is >= 3 bytes
-            lds_sync();
             ExecCtx c;
-            c.sStart = sStart; c.sLL = sLL; c.sOff = sOff; c.sLit = sLit; c.ownerArr = ownerArr; c.outStage = outStage;
+            c.sStart = sStart; c.sLL = sLL; c.sOff = sOff; c.sLit = sLit;
             c.litBase = litBase; c.fdst = fdst; c.dictEnd = dictEnd;
-            c.batchAbs = (int64_t)(bo + pos); c.litRle = litRle; c.small = small;
-            // every lane produces bytes lane, lane+64, ... of the batch (coalesced loads and stores)
-            uint8_t* const bdst = fdst + bo + pos;
-            uint32_t before = 0;                            // sequences that start before this pass
-            for (uint32_t k0 = 0; k0 < total; k0 += 64) {
-                uint32_t const k = k0 + lane;
-                bool const act = k < total;
-                uint32_t own;
-                if (small) {
-                    // owner = (number of sequence starts <= k) - 1, counted with a ballot over the start flags
-                    bool const f = act && startFlag[k] != 0;
-                    unsigned long long const m = __ballot(f);
-                    own = before + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0)) + (f ? 1u : 0u) - 1u;
-                    before += (uint32_t)__builtin_popcountll(m);
-                    if (act) ownerArr[k] = (uint8_t)own;
-                } else own = owner_of(c, act ? k : 0);
-                uint8_t const v = resolve_byte(c, act ? k : 0, k0, act ? own : 0, act);
-                if (act) { bdst[k] = v; if (small) outStage[k] = v; }
+            c.batchAbs = batchAbs; c.litRle = litRle;
+
+            uint8_t* const myDst = fdst + bo + bstart;
+            const uint8_t* const litSrc = litRle ? litBase : litBase + lstart;
+            const uint8_t* const matSrc = absS >= 0 ? fdst + absS : dictEnd + absS;
+            // ---- all loads of the batch ...
+            Run rl, rm;
+            rl.load(litSrc, ll, litRle);
+            rm.load(matSrc, fastLen, false);
+            // first pass of the slow bytes: byte j of the concatenated slow matches -> owner by search over the prefix
+            uint32_t sk = 0;
+            bool sAct = lane < slowTotal;
+            const uint8_t* sSrc = litBase;
+            if (slowTotal) {
+                uint32_t own = 0;
+#pragma unroll
+                for (int step = 32; step >= 1; step >>= 1) own += (sSlowEnd[own + step - 1] <= lane) ? (uint32_t)step : 0u;
+                own = sAct ? own : 0;
+                uint32_t const mlo = sStart[own + 1] - sStart[own] - sLL[own];
+                sk = sStart[own] + sLL[own] + (lane - (sSlowEnd[own] - mlo));
+                sSrc = resolve_source(c, sAct ? sk : 0, own, sAct);
             }
-            if (small && have) startFlag[start] = 0;
+            uint8_t sv = 0;
+            if (slowTotal && sAct) sv = *sSrc;
+            if (s0 + 64 < nValid) {
+                uint32_t const n2 = nValid - s0 - 64 < 64 ? nValid - s0 - 64 : 64;
+                rcN = recs[s0 + 64 + (lane < n2 ? lane : n2)];
+                endN = recs[s0 + 64 + n2].y;
+            }
+            // ---- ... then all stores
+            rl.store(myDst, ll);
+            rm.store(myDst + ll, fastLen);
+            if (slowTotal && sAct) fdst[bo + pos + sk] = sv;
+            copy_long_runs(myDst, litSrc, ll, litRle, lane);
+            copy_long_runs(myDst + ll, matSrc, fastLen, false, lane);
+            // remaining slow bytes, 64 per pass
+            for (uint32_t j0 = 64; j0 < slowTotal; j0 += 64) {
+                uint32_t const j = j0 + lane;
+                bool const act = j < slowTotal;
+                uint32_t own = 0;
+#pragma unroll
+                for (int step = 32; step >= 1; step >>= 1) own += (sSlowEnd[own + step - 1] <= j) ? (uint32_t)step : 0u;
+                own = act ? own : 0;
+                uint32_t const mlo = sStart[own + 1] - sStart[own] - sLL[own];
+                uint32_t const k = sStart[own] + sLL[own] + (j - (sSlowEnd[own] - mlo));
+                const uint8_t* const sp = resolve_source(c, act ? k : 0, own, act);
+                if (act) fdst[bo + pos + k] = *sp;
+            }
             pos += total;
             litPos = __shfl(lstart + ll, 63);
         }
