@@ -517,11 +517,36 @@ __global__ __launch_bounds__(64) void k_literals(BatchParams p)
 }
 
 // ---------------------------------------------------------------- sequence tables
-// Packed decoding cell of a sequence table:
-//   nextState base (9 bits) | nbBits (4) << 9 | nbAdditionalBits (5) << 13 | symbol code (6) << 18.
-// Everything the bit cursor depends on is in the cell; the base value of a code comes from a small LDS
-// side table (LL/ML) or arithmetic (OF) off the serial chain.
-DEVI uint32_t seq_cell(uint32_t nextState, uint32_t nbBits, uint32_t addBits, uint32_t code) { return nextState | (nbBits << 9) | (addBits << 13) | (code << 18); }
+// Packed decoding cell of a sequence table, laid out so that the SUM of the three cells of a sequence
+// (literal length, match length, offset) carries the bit counts the cursor needs:
+//   bits  0-8   nextState base
+//   bits  9-11  symbol-code bits (LL: 1 bit, ML: 2 bits, OF: none); the sum of three cells stays below 2^12 here
+//   bits 12-18  nbBits + nbAdditionalBits      (sum of three <= 89)
+//   bits 19-24  nbAdditionalBits               (sum of three <= 63)
+//   bits 25-28  nbBits
+//   bits 29-31  symbol-code bits, upper part
+// The code bits hold code mod 16 (LL) or code mod 32 (ML); together with nbAdditionalBits they identify the
+// code (LL codes 0-15 and ML codes 0-31 have no additional bits, the higher ones are told apart by theirs).
+// An offset code equals its nbAdditionalBits.  The base value of a code comes from a small LDS side table.
+enum { T_LL = 0, T_OF = 1, T_ML = 2 };
+DEVI uint32_t seq_cell(int t, uint32_t nextState, uint32_t nbBits, uint32_t addBits, uint32_t code)
+{
+    uint32_t const low = t == T_LL ? (code & 15u) : t == T_ML ? (code & 31u) : 0u;
+    uint32_t const sl = t == T_LL ? 1u : t == T_ML ? 2u : 0u;
+    return nextState | ((low & ((1u << sl) - 1u)) << 9) | ((nbBits + addBits) << 12) | (addBits << 19) | (nbBits << 25) | ((low >> sl) << 29);
+}
+DEVI uint32_t cell_addBits(uint32_t c) { return __builtin_amdgcn_ubfe(c, 19, 6); }
+DEVI uint32_t cell_nbBits(uint32_t c) { return __builtin_amdgcn_ubfe(c, 25, 4); }
+DEVI uint32_t cell_llCode(uint32_t c)
+{
+    uint32_t const low = ((c >> 9) & 1u) | ((c >> 29) << 1), a = cell_addBits(c);
+    return low + (a == 0 ? 0u : a >= 13 ? 32u : 16u);
+}
+DEVI uint32_t cell_mlCode(uint32_t c)
+{
+    uint32_t const low = ((c >> 9) & 3u) | ((c >> 29) << 2);
+    return low + (cell_addBits(c) ? 32u : 0u);
+}
 
 __constant__ uint32_t c_LL_base[36] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18, 20, 22, 24, 28, 32, 40,
                                        48, 64, 0x80, 0x100, 0x200, 0x400, 0x800, 0x1000, 0x2000, 0x4000, 0x8000, 0x10000};
@@ -540,7 +565,6 @@ __constant__ int16_t c_ML_defaultNorm[53] = {1, 4, 3, 2, 2, 2, 2, 2, 2, 1, 1, 1,
                                              -1, -1, -1, -1, -1};
 __constant__ int16_t c_OF_defaultNorm[29] = {1, 1, 1, 1, 1, 1, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1};
 
-enum { T_LL = 0, T_OF = 1, T_ML = 2 };
 DEVI uint32_t tbl_max(int t) { return t == T_LL ? 35u : t == T_OF ? 31u : 52u; }
 DEVI uint32_t tbl_addBits(int t, uint32_t code) { return t == T_LL ? c_LL_bits[code] : t == T_OF ? code : c_ML_bits[code]; }
 DEVI uint32_t tbl_maxLog(int t) { return t == T_OF ? 8u : 9u; }
@@ -570,7 +594,7 @@ DEVI void dev_build_seq_table(int t, CellPtr cells, NormPtr norm, NextPtr symNex
         uint32_t const ns = symNext[sym];
         symNext[sym] = (uint16_t)(ns + 1);
         uint32_t const nb = tableLog - hb32(ns);
-        cells[u] = seq_cell((ns << nb) - tableSize, nb, tbl_addBits(t, sym), sym);
+        cells[u] = seq_cell(t, (ns << nb) - tableSize, nb, tbl_addBits(t, sym), sym);
     }
 }
 
@@ -585,7 +609,7 @@ DEVI uint32_t dev_build_from_desc(int t, uint32_t type, const uint8_t* ptr, uint
         if (avail < 1) return kFail;
         uint32_t const sym = ptr[0];
         if (sym > tbl_max(t)) return kFail;
-        cells[0] = seq_cell(0, 0, tbl_addBits(t, sym), sym);
+        cells[0] = seq_cell(t, 0, 0, tbl_addBits(t, sym), sym);
         log = 0;
         return 1;
     }
@@ -790,26 +814,33 @@ __global__ __launch_bounds__(64) void k_sequences(BatchParams p)
 #ifdef ZG_STAMPS
             uint64_t const sl0 = __builtin_readcyclecounter();
 #endif
-            for (uint32_t i = 0; i < n; i++) {
+            // Always a full round: past the last sequence the chain runs on over bits that mean nothing, inside the
+            // staged window (64 x 89 bits fit below any starting cursor) and inside the tables (a state never leaves
+            // its table); its ring entries are ignored, and entry n records the cursor after the last real sequence.
+#pragma unroll 4
+            for (uint32_t i = 0; i < kSeqRound; i++) {
+                // 96 bits below the cursor (top at Q + 1, so that the state bits of any sequence start inside them)
+                uint32_t const P = Q + 1;
+                const uint32_t* const w = inWin + (P >> 5);
+                uint32_t const a0 = w[-3], a1 = w[-2], a2 = w[-1], a3 = w[0];
                 uint32_t const cLL = tLL[sLL], cOF = tOF[sOF], cML = tML[sML];
-                uint32_t tHi, tLo;
-                peek64(inWin, Q, tHi, tLo);
-                uint32_t const n4 = __builtin_amdgcn_ubfe(cLL, 9, 4), n5 = __builtin_amdgcn_ubfe(cML, 9, 4), n6 = __builtin_amdgcn_ubfe(cOF, 9, 4);
-                uint32_t const nEx = __builtin_amdgcn_ubfe(cOF, 13, 5) + __builtin_amdgcn_ubfe(cML, 13, 5) + __builtin_amdgcn_ubfe(cLL, 13, 5);
-                uint32_t const nAll = nEx + n4 + n5 + n6;
-                uint32_t h3;
-                if (__builtin_expect(__any(nAll > 64), 0)) {   // long offsets with long lengths: peek again below the extra bits
-                    uint32_t uHi, uLo;
-                    peek64(inWin, Q - nEx, uHi, uLo);
-                    h3 = uHi;
-                } else h3 = shl_hi(tHi, tLo, nEx);
+                uint32_t const t2 = __builtin_amdgcn_alignbit(a3, a2, P), t1 = __builtin_amdgcn_alignbit(a2, a1, P), t0 = __builtin_amdgcn_alignbit(a1, a0, P);
+                uint32_t const S = cLL + cML + cOF;
+                uint32_t const nEx = __builtin_amdgcn_ubfe(S, 19, 6);
+                // the 32 bits under the additional bits: bit 63 - nEx of (t2:t1:t0) upwards
+                uint32_t const R = 63u - nEx;
+                bool const up = R >= 32u;
+                uint32_t const h3 = __builtin_amdgcn_alignbit(up ? t2 : t1, up ? t1 : t0, R);
                 *(uint4*)(ring + 4 * i) = make_uint4(cLL, cML, cOF, Q);
                 // state update, order LL, ML, OF (:1220-1225); a cell's nextState has its low nbBits clear
-                sLL = (cLL & 0x1FF) | take(h3, 0, n4);
-                sML = (cML & 0x1FF) | take(h3, n4, n5);
-                sOF = (cOF & 0x1FF) | take(h3, n4 + n5, n6);
-                Q -= nAll;
+                uint32_t const n4 = cell_nbBits(cLL), n5 = cell_nbBits(cML), n6 = cell_nbBits(cOF);
+                uint32_t const o4 = 32u - n4, o5 = o4 - n5, o6 = o5 - n6;
+                sLL = (cLL & 0x1FF) | __builtin_amdgcn_ubfe(h3, o4, n4);
+                sML = (cML & 0x1FF) | __builtin_amdgcn_ubfe(h3, o5, n5);
+                sOF = (cOF & 0x1FF) | __builtin_amdgcn_ubfe(h3, o6, n6);
+                Q -= __builtin_amdgcn_ubfe(S, 12, 7);
             }
+            if (n < kSeqRound) Q = ring[4 * n + 3];
 #ifdef ZG_STAMPS
             stampLoop += __builtin_readcyclecounter() - sl0;
 #endif
@@ -837,10 +868,10 @@ __global__ __launch_bounds__(64) void k_sequences(BatchParams p)
             uint32_t const cLL = r.x, cML = r.y, cOF = r.z, Q = r.w;
             uint32_t tHi, tLo;
             peek64(inWin, i < n ? Q : 64u, tHi, tLo);
-            uint32_t const n1 = __builtin_amdgcn_ubfe(cOF, 13, 5), n2 = __builtin_amdgcn_ubfe(cML, 13, 5), n3 = __builtin_amdgcn_ubfe(cLL, 13, 5);
+            uint32_t const n1 = cell_addBits(cOF), n2 = cell_addBits(cML), n3 = cell_addBits(cLL);
             uint32_t const ofRaw = take(tHi, 0, n1);
             uint32_t const h1 = shl_hi(tHi, tLo, n1);
-            uint32_t const llCode = (cLL >> 18) & 63, mlCode = (cML >> 18) & 63;
+            uint32_t const llCode = cell_llCode(cLL), mlCode = cell_mlCode(cML);
             uint32_t const lli = sLLbase[llCode < 36 ? llCode : 0] + take(h1, n2, n3);
             uint32_t const mli = sMLbase[mlCode < 53 ? mlCode : 0] + take(h1, 0, n2);
             bool const valid = i < n;
