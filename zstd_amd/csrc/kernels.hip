@@ -123,7 +123,10 @@ DEVI uint32_t take(uint32_t t, uint32_t skip, uint32_t n) { return __builtin_amd
 // byte of a stream, inside the same 16-byte line of the source buffer's last page.
 DEVI uint4 ld_unit(uintptr_t addr, uintptr_t floor)
 {
-    return *(const uint4*)(addr >= floor ? addr : floor);
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(1))) u32x4* gptr;     // global memory: keeps the load off the flat path
+    u32x4 const x = *(gptr)(addr >= floor ? addr : floor);
+    return make_uint4(x.x, x.y, x.z, x.w);
 }
 
 // ---------------------------------------------------------------- FSE_readNCount (entropy_common.pas:83-256)
@@ -643,6 +646,13 @@ DEVI uint32_t dev_desc_size(int t, uint32_t type, const uint8_t* payload, uint32
 }
 
 // ---------------------------------------------------------------- stage 1: sequences
+// value of the lane D places lower in the same row of 16 lanes (own value where there is none)
+template <int D>
+DEVI uint32_t row_up(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x110 + D, 0xF, 0xF, false); }
+// lane 15 - i of the row (row_mirror): the first lane of a row receives the last lane's value
+DEVI uint32_t row_last_to_first(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x140, 0xF, 0xF, false); }
+// value of the row's first lane in all 16 lanes
+DEVI uint32_t row_first(uint32_t x) { return (uint32_t)__shfl((int)x, (int)(threadIdx.x & ~15u)); }
 constexpr int kSeqJobs = 4;                 // jobs per wave: a 16-lane group each; its first lane decodes, all 16 move data
 constexpr uint32_t kSeqRound = 64;          // sequences per round
 constexpr uint32_t kSeqInDw = 192;          // staged input per round, 16-byte units: 64 x <=89 bits + state init + alignment slack (a peek may also read, and ignore, the dword after it)
@@ -781,8 +791,11 @@ __global__ __launch_bounds__(64) void k_sequences(BatchParams p)
     uintptr_t const floorAddr = (uintptr_t)p.src;
 
     uint32_t sLL = 0, sOF = 0, sML = 0;                    // leader: FSE states
-    Rep3 rep = {kSlot0, kSlot1, kSlot2};                   // group-uniform: stack after the sequences done so far, relative to the block's incoming stack
-    uint32_t outPos = 0, litPos = 0;                       // group-uniform; saturate at 2^31-1 (frames regenerate < 2 GiB, so a saturated position always fails the capacity check)
+    // carried in the group's first lane only: stack after the sequences done so far (relative to the block's incoming
+    // stack) and the positions; saturating at 2^31-1 (frames regenerate < 2 GiB, so a saturated position always
+    // fails the capacity check)
+    Rep3 rep = {kSlot0, kSlot1, kSlot2};
+    uint32_t outPos = 0, litPos = 0;
     uint32_t const nbSeq = blk.nbSeq;
     uint32_t nValid = nbSeq;
 
@@ -794,13 +807,12 @@ __global__ __launch_bounds__(64) void k_sequences(BatchParams p)
         wb = ((top + 15) & ~(uintptr_t)15) - 4 * kSeqInDw;
 #pragma unroll
         for (int k = 0; k < 3; k++) v[k] = ld_unit(wb + 16 * (gl + 16 * k), floorAddr);
+#pragma unroll
+        for (int k = 0; k < 3; k++) *(uint4*)(inWin + 4 * (gl + 16 * k)) = v[k];
     }
     for (uint32_t base = 0; base < nbSeq; base += kSeqRound) {
         uint32_t const n = nbSeq - base < kSeqRound ? nbSeq - base : kSeqRound;
-        lds_sync();      // the previous round's helpers have read the window
-#pragma unroll
-        for (int k = 0; k < 3; k++) *(uint4*)(inWin + 4 * (gl + 16 * k)) = v[k];
-        lds_sync();
+        lds_sync();      // the window is in place
         int const Qbase = (int)(8 * (int64_t)((uintptr_t)sStart - wb));   // window bit index of the stream's first bit
         // ---- leader: the serial chain
         if (leader) {
@@ -847,7 +859,7 @@ __global__ __launch_bounds__(64) void k_sequences(BatchParams p)
             bitsLeft = (int)Q - Qbase;
         }
         lds_sync();
-        bitsLeft = __shfl(bitsLeft, lead);
+        bitsLeft = (int)row_first((uint32_t)bitsLeft);
         // ---- next round's window: issue the loads now, they land while the helpers work
         bool const more = base + kSeqRound < nbSeq;
         uintptr_t wbNext = wb;
@@ -858,23 +870,23 @@ __global__ __launch_bounds__(64) void k_sequences(BatchParams p)
             for (int k = 0; k < 3; k++) v[k] = ld_unit(wbNext + 16 * (gl + 16 * k), floorAddr);
         }
         // ---- all lanes: sequences 4*gl .. 4*gl+3 of this round
-        uint32_t ll[4], len[4];
-        Rep3 tr[4];
+        uint32_t ll[4], len[4], topA[4];
+        Rep3 acc = {kSlot0, kSlot1, kSlot2};    // stack transformation of this lane's sequences so far
         uint32_t firstBad = kSeqRound;          // first sequence of this lane whose extra bits ran past the stream start
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             uint32_t const i = 4 * gl + u;
             uint4 const r = *(const uint4*)(ring + 4 * i);
             uint32_t const cLL = r.x, cML = r.y, cOF = r.z, Q = r.w;
+            bool const valid = i < n;
             uint32_t tHi, tLo;
-            peek64(inWin, i < n ? Q : 64u, tHi, tLo);
+            peek64(inWin, valid ? Q : 64u, tHi, tLo);
             uint32_t const n1 = cell_addBits(cOF), n2 = cell_addBits(cML), n3 = cell_addBits(cLL);
             uint32_t const ofRaw = take(tHi, 0, n1);
             uint32_t const h1 = shl_hi(tHi, tLo, n1);
             uint32_t const llCode = cell_llCode(cLL), mlCode = cell_mlCode(cML);
             uint32_t const lli = sLLbase[llCode < 36 ? llCode : 0] + take(h1, n2, n3);
             uint32_t const mli = sMLbase[mlCode < 53 ? mlCode : 0] + take(h1, 0, n2);
-            bool const valid = i < n;
             if (valid && (int)(Q - (n1 + n2 + n3)) < Qbase && firstBad == kSeqRound) firstBad = i;
             ll[u] = valid ? lli : 0;
             len[u] = valid ? lli + mli : 0;
@@ -883,69 +895,76 @@ __global__ __launch_bounds__(64) void k_sequences(BatchParams p)
             bool const isReal = n1 > 1;
             uint32_t const real = ((1u << n1) - 3u) + ofRaw;
             uint32_t const idx = (n1 ? 1u + ofRaw : 0u) + (llCode == 0 ? 1u : 0u);
-            Rep3 t;
-            t.a = isReal ? (real > 0x7FFFFFFFu ? 0x7FFFFFFFu : real)      // anything that large is beyond every window: kept invalid
-                         : (idx == 0 ? kSlot0 : idx == 1 ? kSlot1 : idx == 2 ? kSlot2 : (kSlot0 | 1u));
-            t.b = (isReal || idx >= 1) ? kSlot0 : kSlot1;
-            t.c = (isReal || idx >= 2) ? kSlot1 : kSlot2;
-            if (!valid) { t.a = kSlot0; t.b = kSlot1; t.c = kSlot2; }
-            tr[u] = t;
+            uint32_t const ta = !valid ? kSlot0
+                              : isReal ? (real > 0x7FFFFFFFu ? 0x7FFFFFFFu : real)      // anything that large is beyond every window: kept invalid
+                                       : (idx == 0 ? kSlot0 : idx == 1 ? kSlot1 : idx == 2 ? kSlot2 : (kSlot0 | 1u));
+            bool const second0 = valid && (isReal || idx >= 1);     // new second entry: old first (else old second)
+            bool const third1 = valid && (isReal || idx >= 2);      // new third entry: old second (else old third)
+            Rep3 nx;
+            nx.a = rep_subst(ta, acc.a, acc.b, acc.c);
+            nx.b = second0 ? acc.a : acc.b;
+            nx.c = third1 ? acc.b : acc.c;
+            acc = nx;
+            topA[u] = acc.a;        // after every sequence the top of the stack is its offset
         }
-        // lane aggregates, then an inclusive scan over the 16 lanes of the group
-        Rep3 agg = rep_compose(rep_compose(rep_compose(tr[0], tr[1]), tr[2]), tr[3]);
+        // lane totals; the group's first lane puts the carried stack and positions in front, so the inclusive scan
+        // over the 16 lanes yields values relative to the block start
         uint32_t sumLen = len[0] + len[1] + len[2] + len[3], sumLL = ll[0] + ll[1] + ll[2] + ll[3];
-        Rep3 incl = agg;
+        Rep3 incl = acc;
+        if (leader) { incl = rep_compose(rep, acc); sumLen += outPos; sumLL += litPos; }
         uint32_t inclLen = sumLen, inclLL = sumLL;
-#pragma unroll
-        for (int d = 1; d < 16; d <<= 1) {
-            Rep3 o;
-            o.a = __shfl_up(incl.a, d, 16); o.b = __shfl_up(incl.b, d, 16); o.c = __shfl_up(incl.c, d, 16);
-            uint32_t const oLen = __shfl_up(inclLen, d, 16), oLL = __shfl_up(inclLL, d, 16);
-            if (gl >= (uint32_t)d) { incl = rep_compose(o, incl); inclLen += oLen; inclLL += oLL; }
+#define ZG_SCAN_STEP(D)                                                                                                  \
+        {                                                                                                                \
+            Rep3 o;                                                                                                      \
+            o.a = row_up<D>(incl.a); o.b = row_up<D>(incl.b); o.c = row_up<D>(incl.c);                                   \
+            uint32_t const oLen = row_up<D>(inclLen), oLL = row_up<D>(inclLL);                                           \
+            if (gl >= D) { incl = rep_compose(o, incl); inclLen += oLen; inclLL += oLL; }                                \
         }
-        // exclusive prefix of this lane = inclusive value of the lane before it, on top of the carry
+        ZG_SCAN_STEP(1) ZG_SCAN_STEP(2) ZG_SCAN_STEP(4) ZG_SCAN_STEP(8)
+#undef ZG_SCAN_STEP
+        // state before this lane's first sequence = inclusive value of the lane before it (the carry itself in the first lane)
         Rep3 ex;
-        ex.a = __shfl_up(incl.a, 1, 16); ex.b = __shfl_up(incl.b, 1, 16); ex.c = __shfl_up(incl.c, 1, 16);
-        uint32_t exLen = __shfl_up(inclLen, 1, 16), exLL = __shfl_up(inclLL, 1, 16);
-        if (gl == 0) { ex.a = kSlot0; ex.b = kSlot1; ex.c = kSlot2; exLen = 0; exLL = 0; }
-        Rep3 cur = rep_compose(rep, ex);
-        uint32_t po = outPos + exLen, pl = litPos + exLL;     // < 2^31 + 64 * 2^18: no wrap
+        ex.a = row_up<1>(incl.a); ex.b = row_up<1>(incl.b); ex.c = row_up<1>(incl.c);
+        uint32_t po = row_up<1>(inclLen), pl = row_up<1>(inclLL);     // < 2^31 + 64 * 2^18: no wrap
+        if (leader) { ex = rep; po = outPos; pl = litPos; }
         uint4 rec[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            cur = rep_compose(cur, tr[u]);
-            rec[u] = make_uint4(cur.a,   // after every sequence the top of the stack is its offset
+            rec[u] = make_uint4(rep_subst(topA[u], ex.a, ex.b, ex.c),
                                 po > 0x7FFFFFFFu ? 0x7FFFFFFFu : po, pl > 0x7FFFFFFFu ? 0x7FFFFFFFu : pl, ll[u]);
             po += len[u]; pl += ll[u];
         }
+        // records out: 64 bytes per lane, 1 KB per group, coalesced; always whole rounds (the buffer has room for them),
+        // so that the number of stores in flight behind the window loads is fixed
+#pragma unroll
+        for (int u = 0; u < 4; u++) out[base + 4 * gl + u] = rec[u];
         // first bad sequence of the round, if any
-        uint32_t bad = firstBad;
-#pragma unroll
-        for (int d = 1; d < 16; d <<= 1) { uint32_t const o = __shfl_xor(bad, d, 16); bad = o < bad ? o : bad; }
-        // records out: 64 bytes per lane, 1 KB per group, coalesced
-#pragma unroll
-        for (int u = 0; u < 4; u++) if (4 * gl + u < n) out[base + 4 * gl + u] = rec[u];
-        if (bad < n) {
+        uint32_t const badLanes = (uint32_t)(__ballot(firstBad != kSeqRound) >> lead) & 0xFFFFu;
+        if (badLanes) {
             // the stream ran dry inside this round: positions stop at the first bad sequence
-            uint32_t const src = lead + (bad >> 2), w = bad & 3;
+            uint32_t const src = lead + (uint32_t)__builtin_ctz(badLanes);
+            uint32_t const bad = __shfl(firstBad, src), w = bad & 3;
             uint32_t const bo = w == 0 ? rec[0].y : w == 1 ? rec[1].y : w == 2 ? rec[2].y : rec[3].y;
             uint32_t const bl = w == 0 ? rec[0].z : w == 1 ? rec[1].z : w == 2 ? rec[2].z : rec[3].z;
             outPos = __shfl(bo, src); litPos = __shfl(bl, src);
             nValid = base + bad;
             break;
         }
-        // carry for the next round: totals of lane 15
+        // carry for the next round: inclusive values of the last lane, handed to the first
         {
-            uint32_t const tl = __shfl(inclLen, lead + 15), tll = __shfl(inclLL, lead + 15);
-            Rep3 tot;
-            tot.a = __shfl(incl.a, lead + 15); tot.b = __shfl(incl.b, lead + 15); tot.c = __shfl(incl.c, lead + 15);
-            rep = rep_compose(rep, tot);
-            outPos += tl; litPos += tll;
+            rep.a = row_last_to_first(incl.a); rep.b = row_last_to_first(incl.b); rep.c = row_last_to_first(incl.c);
+            outPos = row_last_to_first(inclLen); litPos = row_last_to_first(inclLL);
             outPos = outPos > 0x7FFFFFFFu ? 0x7FFFFFFFu : outPos;
             litPos = litPos > 0x7FFFFFFFu ? 0x7FFFFFFFu : litPos;
         }
         wb = wbNext;
+        lds_sync();      // every lane has read the window and the ring
+        if (more) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) *(uint4*)(inWin + 4 * (gl + 16 * k)) = v[k];
+        }
     }
+    wave_sync();         // the round stores are complete before the end record goes on top of them
     if (leader) {
         out[nValid] = make_uint4(0, outPos, litPos, 0);      // end record
         st->seqErr = 0;

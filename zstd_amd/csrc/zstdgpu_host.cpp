@@ -471,7 +471,7 @@ extern "C" zstdgpu_batch* zstdgpu_batch_create(zstdgpu_ctx* ctx, const void* hos
                 if (d.mlType != SET_REPEAT) mlDef = (int32_t)b;
                 d.llSrc = llDef; d.ofSrc = ofDef; d.mlSrc = mlDef;
                 d.seqBufOff = seqOff;
-                seqOff += d.nbSeq + 1;   // + the terminal record
+                seqOff += ((uint64_t)(d.nbSeq + 63) & ~(uint64_t)63) + 1;   // whole rounds of 64 (the sequence kernel stores full rounds) + the terminal record
                 B->hSeqJobs.push_back(b);
             }
         }
