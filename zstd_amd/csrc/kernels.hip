@@ -651,12 +651,12 @@ template <int D>
 DEVI uint32_t row_up(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x110 + D, 0xF, 0xF, false); }
 // lane 15 - i of the row (row_mirror): the first lane of a row receives the last lane's value
 DEVI uint32_t row_last_to_first(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x140, 0xF, 0xF, false); }
-// value of the row's first lane in all 16 lanes
-DEVI uint32_t row_first(uint32_t x) { return (uint32_t)__shfl((int)x, (int)(threadIdx.x & ~15u)); }
-constexpr int kSeqJobs = 4;                 // jobs per wave: a 16-lane group each; its first lane decodes, all 16 move data
+constexpr int kSeqJobs = 16;                // jobs (blocks) per workgroup
+constexpr int kSeqThreads = 64 * 5;         // wave 0: the 16 serial chains, one per lane; waves 1-4: 16 lanes per job
 constexpr uint32_t kSeqRound = 64;          // sequences per round
-constexpr uint32_t kSeqInDw = 192;          // staged input per round, 16-byte units: 64 x <=89 bits + state init + alignment slack (a peek may also read, and ignore, the dword after it)
-constexpr uint32_t kSeqJobWords = 512 + 512 + 256 + 64 + kSeqInDw + 4 * kSeqRound;   // LL | ML | OF cells, {norm, symNext}, input window, record ring
+constexpr uint32_t kWinUnits = 128;         // circular window of the bitstream, 16-byte units (+ 1 mirror unit)
+constexpr uint32_t kWinAhead = 80;          // units kept loaded below the cursor of the round before last
+constexpr uint32_t kSeqJobWords = 512 + 512 + 256 + 4 * (kWinUnits + 1) + 2 * 4 * kSeqRound;   // LL | ML | OF cells, window, two record rings
 constexpr uint32_t kRepIdxShift = 29;
 
 DEVI uint32_t rep_resolve(uint32_t x, const uint32_t* repIn)
@@ -692,291 +692,376 @@ constexpr uint32_t kSlot0 = kSymbolicRep | (0u << kRepIdxShift), kSlot1 = kSymbo
 //   {offset (possibly symbolic), output position, literal position, litLength}, positions block-relative;
 //   the extra last record carries the end positions, so matchLength = next.outPos - outPos - litLength.
 //
-// Work split inside a 16-lane group, in rounds of 64 sequences:
-//   leader lane   the serial chain only: 3 table cells -> 6 bit widths -> bit cursor -> 3 next states
-//                 (ZSTD_decodeSequence's state half, zstd_decompress_block.pas:1092-1101, :1220-1225)
-//   all 16 lanes  4 sequences each: extra bits, base values, repeat-offset resolution by prefix scan,
-//                 positions by prefix sum, coalesced record stores (:1105-1180)
-__global__ __launch_bounds__(64) void k_sequences(BatchParams p)
+// A workgroup of five waves decodes 16 blocks in rounds of 64 sequences:
+//   wave 0, lane j    the serial chain of block j only: 3 table cells -> bit widths -> bit cursor -> 3 next states
+//                     (ZSTD_decodeSequence's state half, zstd_decompress_block.pas:1092-1101, :1220-1225); the cells
+//                     and the cursor of every sequence go into a ring in LDS
+//   waves 1-4         16 lanes per block, 4 sequences per lane, one round behind the chain: extra bits, base
+//                     values, repeat-offset resolution by prefix scan, positions by prefix sum, coalesced record
+//                     stores (:1105-1180); they also build the tables and keep the bitstream window in LDS filled
+// The bitstream sits in a circular LDS window of 2 KB per block, addressed by absolute bit position Q counted from
+// a 16-byte aligned origin 2 KB below the stream's first byte; unit u (16 bytes) lives in slot u mod 128, and slot 0
+// is mirrored behind slot 127 so that a peek never wraps.  While round k+1 is decoded, the helpers that work on
+// round k fetch the units below (cursor after round k) - 80 units; the chain stops a round early in the
+// (pathological) case that it would pass the loaded floor.
+struct SeqCtl {            // per block, in LDS
+    uint32_t fail, nbSeq, logs, Qinit, Qstart;      // logs = logLL | logOF << 8 | logML << 16
+};
+
+DEVI void wg_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// 64 bits below bit Q of a circular window (tHi = bits [Q-32, Q))
+DEVI void peek64c(const uint32_t* win, uint32_t Q, uint32_t& tHi, uint32_t& tLo)
+{
+    uint32_t const d = ((Q >> 5) - 2) & (4 * kWinUnits - 1);
+    uint32_t const a0 = win[d], a1 = win[d + 1], a2 = win[d + 2];
+    tHi = __builtin_amdgcn_alignbit(a2, a1, Q);
+    tLo = __builtin_amdgcn_alignbit(a1, a0, Q);
+}
+
+// 16-byte unit at addr, kept inside [floor, ceil] (whatever lies outside is never interpreted)
+DEVI uint4 ld_unit(uintptr_t addr, uintptr_t floor, uintptr_t ceil) { return ld_unit(addr <= ceil ? addr : ceil, floor); }
+
+__global__ __launch_bounds__(kSeqThreads) void k_sequences(BatchParams p)
 {
     __shared__ __attribute__((aligned(16))) uint32_t lds[kSeqJobs * kSeqJobWords];
     __shared__ uint32_t sLLbase[36], sMLbase[53];
-    uint32_t const lane = threadIdx.x;
-    if (lane < 36) sLLbase[lane] = c_LL_base[lane];
-    if (lane < 53) sMLbase[lane] = c_ML_base[lane];
-    wave_sync();
-    uint32_t const sub = lane >> 4, gl = lane & 15, lead = lane & ~15u;
-    bool const leader = (gl == 0);
-    uint32_t const job = blockIdx.x * kSeqJobs + sub;
-    if (job >= p.nSeqJobs) return;
-    uint32_t const b = p.seqJobs[job];
-    DevBlock const blk = p.blocks[b];
-    uint32_t* const tLL = lds + sub * kSeqJobWords;
+    __shared__ SeqCtl ctl[kSeqJobs];
+    __shared__ uint2 pub[2][kSeqJobs];         // per round parity and block: {cursor after the round, sequences decoded in it}
+    __shared__ uint32_t activeFlag[2];         // per round parity: some block still has sequences to decode in that round
+    uint32_t const tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (tid < 36) sLLbase[tid] = c_LL_base[tid];
+    if (tid < 53) sMLbase[tid] = c_ML_base[tid];
+    if (tid == 0) { activeFlag[0] = 1; activeFlag[1] = 0; }
+
+    // ---------------- helper side set-up (waves 1-4): tables, window, per-block constants
+    uint32_t const gl = lane & 15, lead = lane & ~15u;
+    bool const helper = wave != 0;
+    uint32_t const slot = helper ? (wave - 1) * 4 + (lane >> 4) : (lane & 15);       // block slot inside the workgroup
+    uint32_t const job = blockIdx.x * kSeqJobs + slot;
+    bool const hasJob = job < p.nSeqJobs && (helper || lane < 16);
+    uint32_t* const tLL = lds + slot * kSeqJobWords;
     uint32_t* const tML = tLL + 512;
     uint32_t* const tOF = tML + 512;
-    int16_t* const norm = (int16_t*)(tOF + 256);
-    uint16_t* const symNext = (uint16_t*)(norm + 64);
-    uint32_t* const inWin = tOF + 256 + 64;
-    uint32_t* const ring = inWin + kSeqInDw;
-    DevBlockState* const st = p.state + b;
+    uint32_t* const win = tOF + 256;
+    uint32_t* const ring0 = win + 4 * (kWinUnits + 1);
+    uint32_t const b = hasJob ? p.seqJobs[job] : 0;
 
-#ifdef ZG_STAMPS
-    uint64_t const stamp0 = __builtin_readcyclecounter();
-    uint64_t stampLoop = 0;
-#endif
-    const uint8_t* const payload = p.src + blk.srcOff;
-    uint32_t off = blk.seqHdrOff;
-    uint32_t logLL = 0, logOF = 0, logML = 0;
-    uint32_t failU = 0;
-    if (leader) {
-        uint32_t logs[3] = {0, 0, 0};
-        bool fail = false;
+    // helper-side per-block state
+    DevBlock blk = {};
+    uint32_t failU = 1;
+    uint32_t Qstart = 0, Qend = 0;             // bit position of the stream's first bit; cursor after the last round seen
+    uintptr_t origin = 0, floorAddr = (uintptr_t)p.src, ceilAddr = (uintptr_t)p.src;
+    uint32_t loadedFrom = 0;                   // lowest unit already in the window
+    if (helper && hasJob) {
+        blk = p.blocks[b];
+        const uint8_t* const payload = p.src + blk.srcOff;
+        uint32_t off = blk.seqHdrOff;
+        uint32_t logsPacked = 0;
+        if (gl == 0) {
+            int16_t* const norm = (int16_t*)ring0;          // table-building scratch lives where the rings will be
+            uint16_t* const symNext = (uint16_t*)(norm + 64);
+            uint32_t logs[3] = {0, 0, 0};
+            bool fail = false;
 #pragma unroll
-        for (int t = 0; t < 3; t++) {
-            uint32_t const type = t == T_LL ? blk.llType : t == T_OF ? blk.ofType : blk.mlType;
-            int32_t const srcB = t == T_LL ? blk.llSrc : t == T_OF ? blk.ofSrc : blk.mlSrc;
-            uint32_t* const cells = t == T_LL ? tLL : t == T_OF ? tOF : tML;
-            if (fail) break;
-            if (type != SET_REPEAT) {
-                if (off > blk.cSize) { fail = true; break; }
-                uint32_t const h = dev_build_from_desc(t, type, payload + off, blk.cSize - off, cells, norm, symNext, logs[t]);
-                if (h == kFail) { fail = true; break; }
-                off += h;
-            } else if (srcB == SRC_NONE) {
-                fail = true;
-            } else if (srcB == SRC_DICT) {
-                const uint32_t* const dc = t == T_LL ? p.dict->ll : t == T_OF ? p.dict->of : p.dict->ml;
-                uint32_t const lg = t == T_LL ? p.dict->llLog : t == T_OF ? p.dict->ofLog : p.dict->mlLog;
-                for (uint32_t u = 0; u < (1u << lg); u++) cells[u] = dc[u];
-                logs[t] = lg;
-            } else {
-                // rebuild from the block that defined the table: walk its descriptions up to table t
-                DevBlock const sb = p.blocks[srcB];
-                const uint8_t* const sp = p.src + sb.srcOff;
-                uint32_t o = sb.seqHdrOff;
-                for (int u = 0; u < t && !fail; u++) {
-                    uint32_t const ut = u == T_LL ? sb.llType : sb.ofType;
-                    uint32_t const sz = dev_desc_size(u, ut, sp, o, sb.cSize, norm);
-                    if (sz == kFail) fail = true; else o += sz;
-                }
-                if (!fail) {
-                    uint32_t const stype = t == T_LL ? sb.llType : t == T_OF ? sb.ofType : sb.mlType;
-                    if (o > sb.cSize || dev_build_from_desc(t, stype, sp + o, sb.cSize - o, cells, norm, symNext, logs[t]) == kFail) fail = true;
+            for (int t = 0; t < 3; t++) {
+                uint32_t const type = t == T_LL ? blk.llType : t == T_OF ? blk.ofType : blk.mlType;
+                int32_t const srcB = t == T_LL ? blk.llSrc : t == T_OF ? blk.ofSrc : blk.mlSrc;
+                uint32_t* const cells = t == T_LL ? tLL : t == T_OF ? tOF : tML;
+                if (fail) break;
+                if (type != SET_REPEAT) {
+                    if (off > blk.cSize) { fail = true; break; }
+                    uint32_t const h = dev_build_from_desc(t, type, payload + off, blk.cSize - off, cells, norm, symNext, logs[t]);
+                    if (h == kFail) { fail = true; break; }
+                    off += h;
+                } else if (srcB == SRC_NONE) {
+                    fail = true;
+                } else if (srcB == SRC_DICT) {
+                    const uint32_t* const dc = t == T_LL ? p.dict->ll : t == T_OF ? p.dict->of : p.dict->ml;
+                    uint32_t const lg = t == T_LL ? p.dict->llLog : t == T_OF ? p.dict->ofLog : p.dict->mlLog;
+                    for (uint32_t u = 0; u < (1u << lg); u++) cells[u] = dc[u];
+                    logs[t] = lg;
+                } else {
+                    // rebuild from the block that defined the table: walk its descriptions up to table t
+                    DevBlock const sb = p.blocks[srcB];
+                    const uint8_t* const sp = p.src + sb.srcOff;
+                    uint32_t o = sb.seqHdrOff;
+                    for (int u = 0; u < t && !fail; u++) {
+                        uint32_t const ut = u == T_LL ? sb.llType : sb.ofType;
+                        uint32_t const sz = dev_desc_size(u, ut, sp, o, sb.cSize, norm);
+                        if (sz == kFail) fail = true; else o += sz;
+                    }
+                    if (!fail) {
+                        uint32_t const stype = t == T_LL ? sb.llType : t == T_OF ? sb.ofType : sb.mlType;
+                        if (o > sb.cSize || dev_build_from_desc(t, stype, sp + o, sb.cSize - o, cells, norm, symNext, logs[t]) == kFail) fail = true;
+                    }
                 }
             }
+            if (!fail && off >= blk.cSize) fail = true;                     // BIT_initDStream on an empty stream
+            if (!fail && payload[blk.cSize - 1] == 0) fail = true;          // no end mark
+            failU = fail ? 1u : 0u;
+            logsPacked = logs[T_LL] | (logs[T_OF] << 8) | (logs[T_ML] << 16);
         }
-        if (!fail && off >= blk.cSize) fail = true;                     // BIT_initDStream on an empty stream
-        if (!fail && payload[blk.cSize - 1] == 0) fail = true;          // no end mark
-        failU = fail ? 1u : 0u;
-        logLL = logs[T_LL]; logOF = logs[T_OF]; logML = logs[T_ML];
-    }
-    wave_sync();
-    failU = __shfl(failU, lead);
-    off = __shfl(off, lead);
-    uint4* const out = (uint4*)p.seqBuf + blk.seqBufOff;
-    if (failU) {
-        if (leader) {
-            st->seqErr = E_corruption; st->seqValid = 0; st->tailErr = 0; st->regen = blk.litSize;
-            st->repOut[0] = kSlot0; st->repOut[1] = kSlot1; st->repOut[2] = kSlot2;
-            out[0] = make_uint4(0, 0, 0, 0);
+        wave_sync();
+        failU = __shfl(failU, lead);
+        off = __shfl(off, lead);
+        if (!failU) {
+            const uint8_t* const sStart = payload + off;
+            uint32_t const sSize = blk.cSize - off;
+            uint32_t const bitsLeft = sSize * 8 - (8 - hb32(sStart[sSize - 1]));
+            origin = ((uintptr_t)sStart & ~(uintptr_t)15) - 16 * kWinUnits;
+            Qstart = 8 * (uint32_t)((uintptr_t)sStart - origin);
+            Qend = Qstart + bitsLeft;
+            ceilAddr = ((uintptr_t)sStart + sSize - 1) & ~(uintptr_t)15;
+            // first fill: units (Qend >> 7) - 80 .. the unit of the stream's last byte
+            loadedFrom = (Qend >> 7) - kWinAhead;
+            uint4 v[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) v[k] = ld_unit(origin + 16 * (uintptr_t)(loadedFrom + gl + 16 * k), floorAddr, ceilAddr);
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                uint32_t const u = loadedFrom + gl + 16 * k;
+                if (u <= ((Qend - 1) >> 7)) {
+                    *(uint4*)(win + 4 * (u & (kWinUnits - 1))) = v[k];
+                    if ((u & (kWinUnits - 1)) == 0) *(uint4*)(win + 4 * kWinUnits) = v[k];
+                }
+            }
+            if (gl == 0) { ctl[slot].fail = 0; ctl[slot].nbSeq = blk.nbSeq; ctl[slot].logs = logsPacked; ctl[slot].Qinit = Qend; ctl[slot].Qstart = Qstart; }
+        } else if (gl == 0) {
+            ctl[slot].fail = 1; ctl[slot].nbSeq = 0; ctl[slot].logs = 0; ctl[slot].Qinit = 0; ctl[slot].Qstart = 0;
         }
-        return;
+    } else if (helper && gl == 0) {
+        ctl[slot].fail = 1; ctl[slot].nbSeq = 0; ctl[slot].logs = 0; ctl[slot].Qinit = 0; ctl[slot].Qstart = 0;
     }
-#ifdef ZG_STAMPS
-    uint64_t const stamp1 = __builtin_readcyclecounter();
-#endif
-    const uint8_t* const sStart = payload + off;
-    uint32_t const sSize = blk.cSize - off;
-    int bitsLeft = (int)(sSize * 8) - (int)(8 - hb32(sStart[sSize - 1]));
-    uintptr_t const floorAddr = (uintptr_t)p.src;
+    wg_barrier();
 
-    uint32_t sLL = 0, sOF = 0, sML = 0;                    // leader: FSE states
-    // carried in the group's first lane only: stack after the sequences done so far (relative to the block's incoming
-    // stack) and the positions; saturating at 2^31-1 (frames regenerate < 2 GiB, so a saturated position always
-    // fails the capacity check)
+    // ---------------- chain side set-up (wave 0, lanes 0-15)
+    uint32_t sLL = 0, sOF = 0, sML = 0;        // FSE states
+    uint32_t Q = 0, e1 = 0, e2 = 0;            // cursor; cursor after the previous round and after the one before
+    uint32_t remaining = 0;
+    int dryBelow = 0;                          // a cursor below this is past the stream start by more than the last state update may read
+    if (!helper && lane < 16) {
+        SeqCtl const c = ctl[slot];
+        if (!c.fail) {
+            remaining = c.nbSeq;
+            dryBelow = (int)c.Qstart - 26;
+            Q = e1 = e2 = c.Qinit;
+            // ZSTD_initFseState x3, order LL, OF, ML (:1266-1268), <= 26 bits
+            uint32_t const logLL = c.logs & 255, logOF = (c.logs >> 8) & 255, logML = c.logs >> 16;
+            uint32_t tHi, tLo;
+            peek64c(win, Q, tHi, tLo);
+            sLL = take(tHi, 0, logLL); sOF = take(tHi, logLL, logOF); sML = take(tHi, logLL + logOF, logML);
+            Q -= logLL + logOF + logML;
+        }
+    }
+
+    // helper-side running state; carried in the group's first lane only: stack after the sequences done so far
+    // (relative to the block's incoming stack) and the positions, saturating at 2^31-1 (frames regenerate < 2 GiB,
+    // so a saturated position always fails the capacity check)
     Rep3 rep = {kSlot0, kSlot1, kSlot2};
     uint32_t outPos = 0, litPos = 0;
     uint32_t const nbSeq = blk.nbSeq;
-    uint32_t nValid = nbSeq;
+    uint32_t nValid = nbSeq, seqDone = 0;
+    bool dead = failU != 0;                    // nothing (more) to do for this block on the helper side
+    uint4* const out = (uint4*)p.seqBuf + blk.seqBufOff;
+    uint4* const trash = out + nbSeq + 1;      // 64 spare records per block take the stores of lanes without a sequence
 
-    // stage the top of the unread stream: 48 aligned 16-byte units, 3 per lane
-    uintptr_t wb;
-    uint4 v[3];
-    {
-        uintptr_t const top = (uintptr_t)sStart + (uintptr_t)((bitsLeft + 7) >> 3);
-        wb = ((top + 15) & ~(uintptr_t)15) - 4 * kSeqInDw;
+    for (uint32_t k = 0;; k++) {
+        uint32_t const par = k & 1;
+        bool const act = activeFlag[par] != 0;
+        if (!helper) {
+            // ---- the serial chains, round k
+            if (act) {
+                uint32_t n = 0;
+                uint32_t* const ring = ring0 + par * 4 * kSeqRound;
+                if (remaining) {
+                    // lowest bit the window is known to hold, plus what 4 sequences and a 96-bit peek can reach
+                    uint32_t const Qlim = ((e2 >> 7) - kWinAhead) * 128 + 96 + 4 * 89;
+                    uint32_t i = 0;
+                    for (; i < kSeqRound; i += 4) {
+                        if (Q < Qlim) break;
+                        // Past the block's last sequence the chain runs on over bits that mean nothing, inside the window
+                        // and inside the tables (a state never leaves its table); those ring entries are ignored, and
+                        // entry n records the cursor after the last real sequence.
 #pragma unroll
-        for (int k = 0; k < 3; k++) v[k] = ld_unit(wb + 16 * (gl + 16 * k), floorAddr);
-#pragma unroll
-        for (int k = 0; k < 3; k++) *(uint4*)(inWin + 4 * (gl + 16 * k)) = v[k];
-    }
-    for (uint32_t base = 0; base < nbSeq; base += kSeqRound) {
-        uint32_t const n = nbSeq - base < kSeqRound ? nbSeq - base : kSeqRound;
-        lds_sync();      // the window is in place
-        int const Qbase = (int)(8 * (int64_t)((uintptr_t)sStart - wb));   // window bit index of the stream's first bit
-        // ---- leader: the serial chain
-        if (leader) {
-            uint32_t Q = (uint32_t)(Qbase + bitsLeft);   // >= 295: a round consumes < 5723 bits of a window that holds >= 6017
-            if (base == 0) {   // ZSTD_initFseState x3, order LL, OF, ML (:1266-1268), <= 26 bits
-                uint32_t tHi, tLo;
-                peek64(inWin, Q, tHi, tLo);
-                sLL = take(tHi, 0, logLL); sOF = take(tHi, logLL, logOF); sML = take(tHi, logLL + logOF, logML);
-                Q -= logLL + logOF + logML;
+                        for (uint32_t j = 0; j < 4; j++) {
+                            // 96 bits below the cursor (top at Q + 1, so that the state bits of any sequence start inside them)
+                            uint32_t const T = Q - 95;
+                            const uint32_t* const w = win + __builtin_amdgcn_ubfe(T, 5, 9);
+                            uint32_t const a0 = w[0], a1 = w[1], a2 = w[2], a3 = w[3];
+                            uint32_t const cLL = tLL[sLL], cOF = tOF[sOF], cML = tML[sML];
+                            uint32_t const t2 = __builtin_amdgcn_alignbit(a3, a2, T), t1 = __builtin_amdgcn_alignbit(a2, a1, T), t0 = __builtin_amdgcn_alignbit(a1, a0, T);
+                            uint32_t const S = cLL + cML + cOF;
+                            uint32_t const nEx = __builtin_amdgcn_ubfe(S, 19, 6);
+                            // the 32 bits under the additional bits: bit 63 - nEx of (t2:t1:t0) upwards
+                            uint32_t const R = 63u - nEx;
+                            bool const up = R >= 32u;
+                            uint32_t const h3 = __builtin_amdgcn_alignbit(up ? t2 : t1, up ? t1 : t0, R);
+                            *(uint4*)(ring + 4 * (i + j)) = make_uint4(cLL, cML, cOF, Q);
+                            // state update, order LL, ML, OF (:1220-1225); a cell's nextState has its low nbBits clear
+                            uint32_t const n4 = cell_nbBits(cLL), n5 = cell_nbBits(cML), n6 = cell_nbBits(cOF);
+                            uint32_t const o4 = 32u - n4, o5 = o4 - n5, o6 = o5 - n6;
+                            sLL = (cLL & 0x1FF) | __builtin_amdgcn_ubfe(h3, o4, n4);
+                            sML = (cML & 0x1FF) | __builtin_amdgcn_ubfe(h3, o5, n5);
+                            sOF = (cOF & 0x1FF) | __builtin_amdgcn_ubfe(h3, o6, n6);
+                            Q -= __builtin_amdgcn_ubfe(S, 12, 7);
+                        }
+                    }
+                    n = i < remaining ? i : remaining;
+                    if (n < i) Q = ring[4 * n + 3];
+                    remaining -= n;
+                    // the stream ran dry: some sequence of this round is flagged by the helpers, nothing after it counts
+                    if ((int)Q < dryBelow) remaining = 0;
+                    e2 = e1; e1 = Q;
+                }
+                if (lane < 16) pub[par][lane] = make_uint2(Q, n);
+                bool const anyLeft = __any(remaining != 0);
+                if (lane == 0) activeFlag[par ^ 1] = anyLeft ? 1u : 0u;
             }
-#ifdef ZG_STAMPS
-            uint64_t const sl0 = __builtin_readcyclecounter();
-#endif
-            // Always a full round: past the last sequence the chain runs on over bits that mean nothing, inside the
-            // staged window (64 x 89 bits fit below any starting cursor) and inside the tables (a state never leaves
-            // its table); its ring entries are ignored, and entry n records the cursor after the last real sequence.
-#pragma unroll 4
-            for (uint32_t i = 0; i < kSeqRound; i++) {
-                // 96 bits below the cursor (top at Q + 1, so that the state bits of any sequence start inside them)
-                uint32_t const P = Q + 1;
-                const uint32_t* const w = inWin + (P >> 5);
-                uint32_t const a0 = w[-3], a1 = w[-2], a2 = w[-1], a3 = w[0];
-                uint32_t const cLL = tLL[sLL], cOF = tOF[sOF], cML = tML[sML];
-                uint32_t const t2 = __builtin_amdgcn_alignbit(a3, a2, P), t1 = __builtin_amdgcn_alignbit(a2, a1, P), t0 = __builtin_amdgcn_alignbit(a1, a0, P);
-                uint32_t const S = cLL + cML + cOF;
-                uint32_t const nEx = __builtin_amdgcn_ubfe(S, 19, 6);
-                // the 32 bits under the additional bits: bit 63 - nEx of (t2:t1:t0) upwards
-                uint32_t const R = 63u - nEx;
-                bool const up = R >= 32u;
-                uint32_t const h3 = __builtin_amdgcn_alignbit(up ? t2 : t1, up ? t1 : t0, R);
-                *(uint4*)(ring + 4 * i) = make_uint4(cLL, cML, cOF, Q);
-                // state update, order LL, ML, OF (:1220-1225); a cell's nextState has its low nbBits clear
-                uint32_t const n4 = cell_nbBits(cLL), n5 = cell_nbBits(cML), n6 = cell_nbBits(cOF);
-                uint32_t const o4 = 32u - n4, o5 = o4 - n5, o6 = o5 - n6;
-                sLL = (cLL & 0x1FF) | __builtin_amdgcn_ubfe(h3, o4, n4);
-                sML = (cML & 0x1FF) | __builtin_amdgcn_ubfe(h3, o5, n5);
-                sOF = (cOF & 0x1FF) | __builtin_amdgcn_ubfe(h3, o6, n6);
-                Q -= __builtin_amdgcn_ubfe(S, 12, 7);
-            }
-            if (n < kSeqRound) Q = ring[4 * n + 3];
-#ifdef ZG_STAMPS
-            stampLoop += __builtin_readcyclecounter() - sl0;
-#endif
-            bitsLeft = (int)Q - Qbase;
-        }
-        lds_sync();
-        bitsLeft = (int)row_first((uint32_t)bitsLeft);
-        // ---- next round's window: issue the loads now, they land while the helpers work
-        bool const more = base + kSeqRound < nbSeq;
-        uintptr_t wbNext = wb;
-        if (more) {
-            uintptr_t const top = (uintptr_t)sStart + (uintptr_t)((bitsLeft > 0 ? bitsLeft + 7 : 0) >> 3);
-            wbNext = ((top + 15) & ~(uintptr_t)15) - 4 * kSeqInDw;
+        } else if (k >= 1 && !dead) {
+            // ---- helpers, round k-1
+            uint32_t const hp = par ^ 1;
+            uint2 const pb = pub[hp][slot];
+            uint32_t const n = pb.y;
+            const uint32_t* const ring = ring0 + hp * 4 * kSeqRound;
+            if (n) {
+                uint32_t const base = seqDone;
+                bool const more = base + n < nbSeq;
+                // units the chain may need two rounds from now: down to (cursor after this round) - 80 units
+                Qend = pb.x;
+                uint32_t const newFrom = (Qend >> 7) - kWinAhead;     // <= loadedFrom; at most 46 units below it
+                uint4 v[3];
 #pragma unroll
-            for (int k = 0; k < 3; k++) v[k] = ld_unit(wbNext + 16 * (gl + 16 * k), floorAddr);
-        }
-        // ---- all lanes: sequences 4*gl .. 4*gl+3 of this round
-        uint32_t ll[4], len[4], topA[4];
-        Rep3 acc = {kSlot0, kSlot1, kSlot2};    // stack transformation of this lane's sequences so far
-        uint32_t firstBad = kSeqRound;          // first sequence of this lane whose extra bits ran past the stream start
+                for (int q = 0; q < 3; q++) v[q] = ld_unit(origin + 16 * (uintptr_t)(newFrom + gl + 16 * q), floorAddr, ceilAddr);
+                // ---- sequences 4*gl .. 4*gl+3 of this round
+                uint32_t ll[4], len[4], topA[4];
+                Rep3 acc = {kSlot0, kSlot1, kSlot2};    // stack transformation of this lane's sequences so far
+                uint32_t firstBad = kSeqRound;          // first sequence of this lane whose extra bits ran past the stream start
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            uint32_t const i = 4 * gl + u;
-            uint4 const r = *(const uint4*)(ring + 4 * i);
-            uint32_t const cLL = r.x, cML = r.y, cOF = r.z, Q = r.w;
-            bool const valid = i < n;
-            uint32_t tHi, tLo;
-            peek64(inWin, valid ? Q : 64u, tHi, tLo);
-            uint32_t const n1 = cell_addBits(cOF), n2 = cell_addBits(cML), n3 = cell_addBits(cLL);
-            uint32_t const ofRaw = take(tHi, 0, n1);
-            uint32_t const h1 = shl_hi(tHi, tLo, n1);
-            uint32_t const llCode = cell_llCode(cLL), mlCode = cell_mlCode(cML);
-            uint32_t const lli = sLLbase[llCode < 36 ? llCode : 0] + take(h1, n2, n3);
-            uint32_t const mli = sMLbase[mlCode < 53 ? mlCode : 0] + take(h1, 0, n2);
-            if (valid && (int)(Q - (n1 + n2 + n3)) < Qbase && firstBad == kSeqRound) firstBad = i;
-            ll[u] = valid ? lli : 0;
-            len[u] = valid ? lli + mli : 0;
-            // repeat-offset step of this sequence as a stack transformation (:1105-1161):
-            //   real offset v: (v, s0, s1);  repeat idx 0: (s0, s1, s2), 1: (s1, s0, s2), 2: (s2, s0, s1), 3: (s0 - 1, s0, s1)
-            bool const isReal = n1 > 1;
-            uint32_t const real = ((1u << n1) - 3u) + ofRaw;
-            uint32_t const idx = (n1 ? 1u + ofRaw : 0u) + (llCode == 0 ? 1u : 0u);
-            uint32_t const ta = !valid ? kSlot0
-                              : isReal ? (real > 0x7FFFFFFFu ? 0x7FFFFFFFu : real)      // anything that large is beyond every window: kept invalid
-                                       : (idx == 0 ? kSlot0 : idx == 1 ? kSlot1 : idx == 2 ? kSlot2 : (kSlot0 | 1u));
-            bool const second0 = valid && (isReal || idx >= 1);     // new second entry: old first (else old second)
-            bool const third1 = valid && (isReal || idx >= 2);      // new third entry: old second (else old third)
-            Rep3 nx;
-            nx.a = rep_subst(ta, acc.a, acc.b, acc.c);
-            nx.b = second0 ? acc.a : acc.b;
-            nx.c = third1 ? acc.b : acc.c;
-            acc = nx;
-            topA[u] = acc.a;        // after every sequence the top of the stack is its offset
-        }
-        // lane totals; the group's first lane puts the carried stack and positions in front, so the inclusive scan
-        // over the 16 lanes yields values relative to the block start
-        uint32_t sumLen = len[0] + len[1] + len[2] + len[3], sumLL = ll[0] + ll[1] + ll[2] + ll[3];
-        Rep3 incl = acc;
-        if (leader) { incl = rep_compose(rep, acc); sumLen += outPos; sumLL += litPos; }
-        uint32_t inclLen = sumLen, inclLL = sumLL;
+                for (int u = 0; u < 4; u++) {
+                    uint32_t const i = 4 * gl + u;
+                    uint4 const r = *(const uint4*)(ring + 4 * i);
+                    uint32_t const cLL = r.x, cML = r.y, cOF = r.z, Qs = r.w;
+                    bool const valid = i < n;
+                    uint32_t tHi, tLo;
+                    peek64c(win, Qs, tHi, tLo);
+                    uint32_t const n1 = cell_addBits(cOF), n2 = cell_addBits(cML), n3 = cell_addBits(cLL);
+                    uint32_t const ofRaw = take(tHi, 0, n1);
+                    uint32_t const h1 = shl_hi(tHi, tLo, n1);
+                    uint32_t const llCode = cell_llCode(cLL), mlCode = cell_mlCode(cML);
+                    uint32_t const lli = sLLbase[llCode < 36 ? llCode : 0] + take(h1, n2, n3);
+                    uint32_t const mli = sMLbase[mlCode < 53 ? mlCode : 0] + take(h1, 0, n2);
+                    if (valid && (int)(Qs - (n1 + n2 + n3)) < (int)Qstart && firstBad == kSeqRound) firstBad = i;
+                    ll[u] = valid ? lli : 0;
+                    len[u] = valid ? lli + mli : 0;
+                    // repeat-offset step of this sequence as a stack transformation (:1105-1161):
+                    //   real offset v: (v, s0, s1);  repeat idx 0: (s0, s1, s2), 1: (s1, s0, s2), 2: (s2, s0, s1), 3: (s0 - 1, s0, s1)
+                    bool const isReal = n1 > 1;
+                    uint32_t const real = ((1u << n1) - 3u) + ofRaw;
+                    uint32_t const idx = (n1 ? 1u + ofRaw : 0u) + (llCode == 0 ? 1u : 0u);
+                    uint32_t const ta = !valid ? kSlot0
+                                      : isReal ? (real > 0x7FFFFFFFu ? 0x7FFFFFFFu : real)      // anything that large is beyond every window: kept invalid
+                                               : (idx == 0 ? kSlot0 : idx == 1 ? kSlot1 : idx == 2 ? kSlot2 : (kSlot0 | 1u));
+                    bool const second0 = valid && (isReal || idx >= 1);     // new second entry: old first (else old second)
+                    bool const third1 = valid && (isReal || idx >= 2);      // new third entry: old second (else old third)
+                    Rep3 nx;
+                    nx.a = rep_subst(ta, acc.a, acc.b, acc.c);
+                    nx.b = second0 ? acc.a : acc.b;
+                    nx.c = third1 ? acc.b : acc.c;
+                    acc = nx;
+                    topA[u] = acc.a;        // after every sequence the top of the stack is its offset
+                }
+                // lane totals; the group's first lane puts the carried stack and positions in front, so the inclusive
+                // scan over the 16 lanes yields values relative to the block start
+                uint32_t sumLen = len[0] + len[1] + len[2] + len[3], sumLL = ll[0] + ll[1] + ll[2] + ll[3];
+                Rep3 incl = acc;
+                if (gl == 0) { incl = rep_compose(rep, acc); sumLen += outPos; sumLL += litPos; }
+                uint32_t inclLen = sumLen, inclLL = sumLL;
 #define ZG_SCAN_STEP(D)                                                                                                  \
-        {                                                                                                                \
-            Rep3 o;                                                                                                      \
-            o.a = row_up<D>(incl.a); o.b = row_up<D>(incl.b); o.c = row_up<D>(incl.c);                                   \
-            uint32_t const oLen = row_up<D>(inclLen), oLL = row_up<D>(inclLL);                                           \
-            if (gl >= D) { incl = rep_compose(o, incl); inclLen += oLen; inclLL += oLL; }                                \
-        }
-        ZG_SCAN_STEP(1) ZG_SCAN_STEP(2) ZG_SCAN_STEP(4) ZG_SCAN_STEP(8)
+                {                                                                                                        \
+                    Rep3 o;                                                                                              \
+                    o.a = row_up<D>(incl.a); o.b = row_up<D>(incl.b); o.c = row_up<D>(incl.c);                           \
+                    uint32_t const oLen = row_up<D>(inclLen), oLL = row_up<D>(inclLL);                                   \
+                    if (gl >= D) { incl = rep_compose(o, incl); inclLen += oLen; inclLL += oLL; }                        \
+                }
+                ZG_SCAN_STEP(1) ZG_SCAN_STEP(2) ZG_SCAN_STEP(4) ZG_SCAN_STEP(8)
 #undef ZG_SCAN_STEP
-        // state before this lane's first sequence = inclusive value of the lane before it (the carry itself in the first lane)
-        Rep3 ex;
-        ex.a = row_up<1>(incl.a); ex.b = row_up<1>(incl.b); ex.c = row_up<1>(incl.c);
-        uint32_t po = row_up<1>(inclLen), pl = row_up<1>(inclLL);     // < 2^31 + 64 * 2^18: no wrap
-        if (leader) { ex = rep; po = outPos; pl = litPos; }
-        uint4 rec[4];
+                // state before this lane's first sequence = inclusive value of the lane before it (the carry itself in the first lane)
+                Rep3 ex;
+                ex.a = row_up<1>(incl.a); ex.b = row_up<1>(incl.b); ex.c = row_up<1>(incl.c);
+                uint32_t po = row_up<1>(inclLen), pl = row_up<1>(inclLL);     // < 2^31 + 64 * 2^18: no wrap
+                if (gl == 0) { ex = rep; po = outPos; pl = litPos; }
+                uint4 rec[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            rec[u] = make_uint4(rep_subst(topA[u], ex.a, ex.b, ex.c),
-                                po > 0x7FFFFFFFu ? 0x7FFFFFFFu : po, pl > 0x7FFFFFFFu ? 0x7FFFFFFFu : pl, ll[u]);
-            po += len[u]; pl += ll[u];
-        }
-        // records out: 64 bytes per lane, 1 KB per group, coalesced; always whole rounds (the buffer has room for them),
-        // so that the number of stores in flight behind the window loads is fixed
+                for (int u = 0; u < 4; u++) {
+                    rec[u] = make_uint4(rep_subst(topA[u], ex.a, ex.b, ex.c),
+                                        po > 0x7FFFFFFFu ? 0x7FFFFFFFu : po, pl > 0x7FFFFFFFu ? 0x7FFFFFFFu : pl, ll[u]);
+                    po += len[u]; pl += ll[u];
+                }
+                // records out: 64 bytes per lane, 1 KB per group, coalesced; every lane stores four records (lanes without
+                // a sequence into the spare area), so that the number of stores in flight behind the window loads is fixed
 #pragma unroll
-        for (int u = 0; u < 4; u++) out[base + 4 * gl + u] = rec[u];
-        // first bad sequence of the round, if any
-        uint32_t const badLanes = (uint32_t)(__ballot(firstBad != kSeqRound) >> lead) & 0xFFFFu;
-        if (badLanes) {
-            // the stream ran dry inside this round: positions stop at the first bad sequence
-            uint32_t const src = lead + (uint32_t)__builtin_ctz(badLanes);
-            uint32_t const bad = __shfl(firstBad, src), w = bad & 3;
-            uint32_t const bo = w == 0 ? rec[0].y : w == 1 ? rec[1].y : w == 2 ? rec[2].y : rec[3].y;
-            uint32_t const bl = w == 0 ? rec[0].z : w == 1 ? rec[1].z : w == 2 ? rec[2].z : rec[3].z;
-            outPos = __shfl(bo, src); litPos = __shfl(bl, src);
-            nValid = base + bad;
-            break;
-        }
-        // carry for the next round: inclusive values of the last lane, handed to the first
-        {
-            rep.a = row_last_to_first(incl.a); rep.b = row_last_to_first(incl.b); rep.c = row_last_to_first(incl.c);
-            outPos = row_last_to_first(inclLen); litPos = row_last_to_first(inclLL);
-            outPos = outPos > 0x7FFFFFFFu ? 0x7FFFFFFFu : outPos;
-            litPos = litPos > 0x7FFFFFFFu ? 0x7FFFFFFFu : litPos;
-        }
-        wb = wbNext;
-        lds_sync();      // every lane has read the window and the ring
-        if (more) {
+                for (int u = 0; u < 4; u++) {
+                    uint32_t const i = 4 * gl + u;
+                    uint4* const dstRec = i < n ? out + base + i : trash + i;
+                    *dstRec = rec[u];
+                }
+                // first bad sequence of the round, if any
+                uint32_t const badLanes = (uint32_t)(__ballot(firstBad != kSeqRound) >> lead) & 0xFFFFu;
+                if (badLanes) {
+                    // the stream ran dry inside this round: positions stop at the first bad sequence
+                    uint32_t const src = lead + (uint32_t)__builtin_ctz(badLanes);
+                    uint32_t const bad = __shfl(firstBad, src), w = bad & 3;
+                    uint32_t const bo = w == 0 ? rec[0].y : w == 1 ? rec[1].y : w == 2 ? rec[2].y : rec[3].y;
+                    uint32_t const bl = w == 0 ? rec[0].z : w == 1 ? rec[1].z : w == 2 ? rec[2].z : rec[3].z;
+                    outPos = __shfl(bo, src); litPos = __shfl(bl, src);
+                    nValid = base + bad;
+                    dead = true;
+                } else {
+                    // carry for the next round: inclusive values of the last lane, handed to the first
+                    rep.a = row_last_to_first(incl.a); rep.b = row_last_to_first(incl.b); rep.c = row_last_to_first(incl.c);
+                    outPos = row_last_to_first(inclLen); litPos = row_last_to_first(inclLL);
+                    outPos = outPos > 0x7FFFFFFFu ? 0x7FFFFFFFu : outPos;
+                    litPos = litPos > 0x7FFFFFFFu ? 0x7FFFFFFFu : litPos;
+                    seqDone = base + n;
+                    if (!more) dead = true;
+                }
+                // window units for the chain, two rounds ahead (nobody reads these slots now)
 #pragma unroll
-            for (int k = 0; k < 3; k++) *(uint4*)(inWin + 4 * (gl + 16 * k)) = v[k];
+                for (int q = 0; q < 3; q++) {
+                    uint32_t const u = newFrom + gl + 16 * q;
+                    if (u < loadedFrom) {
+                        *(uint4*)(win + 4 * (u & (kWinUnits - 1))) = v[q];
+                        if ((u & (kWinUnits - 1)) == 0) *(uint4*)(win + 4 * kWinUnits) = v[q];
+                    }
+                }
+                loadedFrom = newFrom;
+            }
         }
+        wg_barrier();
+        if (!act || k > (1u << 16)) break;     // (every round with work left decodes at least 4 sequences of each unfinished block)
     }
-    wave_sync();         // the round stores are complete before the end record goes on top of them
-    if (leader) {
-        out[nValid] = make_uint4(0, outPos, litPos, 0);      // end record
-        st->seqErr = 0;
-        st->seqValid = nValid;
-        // after the last sequence the reader must be at (or, through the last state update, past) the stream start (:1301)
-        st->tailErr = (nValid == nbSeq && bitsLeft > 0) ? (uint32_t)E_corruption : 0u;
-        st->regen = (uint64_t)outPos + (litPos <= blk.litSize ? blk.litSize - litPos : 0);
-        st->repOut[0] = rep.a; st->repOut[1] = rep.b; st->repOut[2] = rep.c;
-#ifdef ZG_STAMPS
-        // diagnostic build: cycles spent building tables, in the decode loops, and in total, per block
-        if (p.dbg) { uint64_t const e = __builtin_readcyclecounter(); p.dbg[4 * b] = stamp1 - stamp0; p.dbg[4 * b + 1] = stampLoop; p.dbg[4 * b + 2] = e - stamp0; p.dbg[4 * b + 3] = nbSeq; }
-#endif
+    wave_sync();         // the round stores are complete before the end record goes on top of one of them
+    if (helper && hasJob && gl == 0) {
+        DevBlockState* const st = p.state + b;
+        if (failU) {
+            st->seqErr = E_corruption; st->seqValid = 0; st->tailErr = 0; st->regen = blk.litSize;
+            st->repOut[0] = kSlot0; st->repOut[1] = kSlot1; st->repOut[2] = kSlot2;
+            out[0] = make_uint4(0, 0, 0, 0);
+        } else {
+            out[nValid] = make_uint4(0, outPos, litPos, 0);      // end record
+            st->seqErr = 0;
+            st->seqValid = nValid;
+            // after the last sequence the reader must be at (or, through the last state update, past) the stream start (:1301)
+            st->tailErr = (nValid == nbSeq && (int)Qend > (int)Qstart) ? (uint32_t)E_corruption : 0u;
+            st->regen = (uint64_t)outPos + (litPos <= blk.litSize ? blk.litSize - litPos : 0);
+            st->repOut[0] = rep.a; st->repOut[1] = rep.b; st->repOut[2] = rep.c;
+        }
     }
 }
 
@@ -1433,7 +1518,7 @@ void launch_literals(const BatchParams& p, void* stream)
 void launch_sequences(const BatchParams& p, void* stream)
 {
     if (!p.nSeqJobs) return;
-    hipLaunchKernelGGL(k_sequences, dim3((p.nSeqJobs + kSeqJobs - 1) / kSeqJobs), dim3(64), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(k_sequences, dim3((p.nSeqJobs + kSeqJobs - 1) / kSeqJobs), dim3(kSeqThreads), 0, (hipStream_t)stream, p);
 }
 void launch_layout(const BatchParams& p, void* stream)
 {

@@ -471,7 +471,7 @@ extern "C" zstdgpu_batch* zstdgpu_batch_create(zstdgpu_ctx* ctx, const void* hos
                 if (d.mlType != SET_REPEAT) mlDef = (int32_t)b;
                 d.llSrc = llDef; d.ofSrc = ofDef; d.mlSrc = mlDef;
                 d.seqBufOff = seqOff;
-                seqOff += ((uint64_t)(d.nbSeq + 63) & ~(uint64_t)63) + 1;   // whole rounds of 64 (the sequence kernel stores full rounds) + the terminal record
+                seqOff += (uint64_t)d.nbSeq + 1 + 64;   // + the terminal record + 64 spare records (the sequence kernel stores whole rounds)
                 B->hSeqJobs.push_back(b);
             }
         }
@@ -525,8 +525,8 @@ extern "C" size_t zstdgpu_batch_decode(zstdgpu_batch* B, const void* devSrc, voi
     }
 #ifdef ZG_STAMPS
     static uint64_t* dbgBuf = nullptr; static size_t dbgCap = 0;
-    if (dbgCap < p.nBlocks) { hipFree(dbgBuf); hipMalloc((void**)&dbgBuf, (size_t)p.nBlocks * 32); dbgCap = p.nBlocks; }
-    hipMemsetAsync(dbgBuf, 0, (size_t)p.nBlocks * 32, s);
+    if (dbgCap < p.nBlocks) { hipFree(dbgBuf); hipMalloc((void**)&dbgBuf, (size_t)p.nBlocks * 64); dbgCap = p.nBlocks; }
+    hipMemsetAsync(dbgBuf, 0, (size_t)p.nBlocks * 64, s);
     p.dbg = dbgBuf;
 #endif
     bool const prof = B->profiling && B->evReady;
@@ -546,12 +546,12 @@ extern "C" size_t zstdgpu_batch_decode(zstdgpu_batch* B, const void* devSrc, voi
 #ifdef ZG_STAMPS
     {   // diagnostic build: print where the sequence stage spends its cycles
         hipStreamSynchronize(s);
-        std::vector<uint64_t> h((size_t)p.nBlocks * 4);
+        std::vector<uint64_t> h((size_t)p.nBlocks * 8);
         hipMemcpy(h.data(), dbgBuf, h.size() * 8, hipMemcpyDeviceToHost);
-        double tb = 0, lp = 0, tot = 0, ns = 0; uint64_t mx = 0; size_t n = 0;
-        for (size_t i = 0; i < p.nBlocks; i++) if (h[4 * i + 2]) { tb += h[4 * i]; lp += h[4 * i + 1]; tot += h[4 * i + 2]; ns += h[4 * i + 3]; if (h[4 * i + 2] > mx) mx = h[4 * i + 2]; n++; }
-        if (n) fprintf(stderr, "[stamps] k_sequences per block: tables %.0f  decode loops %.0f  total %.0f (max %llu) ticks; %.0f seqs; %.1f loop ticks/seq\n",
-                       tb / n, lp / n, tot / n, (unsigned long long)mx, ns / n, lp / ns);
+        double tb = 0, lp = 0, tot = 0, ns = 0, a = 0, bb = 0, c = 0, d = 0; uint64_t mx = 0; size_t n = 0;
+        for (size_t i = 0; i < p.nBlocks; i++) if (h[8 * i + 2]) { tb += h[8 * i]; lp += h[8 * i + 1]; tot += h[8 * i + 2]; ns += h[8 * i + 3]; a += h[8 * i + 4]; bb += h[8 * i + 5]; c += h[8 * i + 6]; d += h[8 * i + 7]; if (h[8 * i + 2] > mx) mx = h[8 * i + 2]; n++; }
+        if (n) fprintf(stderr, "[stamps] k_sequences per block: tables %.0f  decode loops %.0f  total %.0f (max %llu) ticks; %.0f seqs; %.1f loop ticks/seq; helpers: extract %.0f scan+records %.0f stores+carry %.0f window %.0f\n",
+                       tb / n, lp / n, tot / n, (unsigned long long)mx, ns / n, lp / ns, a / n, bb / n, c / n, d / n);
     }
 #endif
     return hipGetLastError() == hipSuccess ? 0 : mkerr(E_generic);
