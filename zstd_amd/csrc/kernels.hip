@@ -1132,9 +1132,11 @@ DEVI uint32_t owner_of(const ExecCtx& c, uint32_t q)
 // source is followed in turn -- each hop lands in an earlier sequence, so the walk ends; overlapping
 // matches (offset < matchLength) fold with a modulo.  This replaces the byte-serial
 // ZSTD_overlapCopy8 / ZSTD_safecopy (zstd_decompress_block.pas:793-885).  Wave-uniform loop.
-DEVI const uint8_t* resolve_source(const ExecCtx& c, uint32_t k, uint32_t own, bool active)
+// `litAt` receives the literal position (block-relative) when the byte is a literal, else 0xFFFFFFFF.
+DEVI const uint8_t* resolve_source(const ExecCtx& c, uint32_t k, uint32_t own, bool active, uint32_t& litAt)
 {
     const uint8_t* ptr = c.litBase;
+    litAt = 0xFFFFFFFFu;
     uint32_t q = k;
     bool pending = active;
     for (int hop = 0; hop < 66 && __any(pending); hop++) {
@@ -1142,7 +1144,8 @@ DEVI const uint8_t* resolve_source(const ExecCtx& c, uint32_t k, uint32_t own, b
         uint32_t const r = q - st, sll = c.sLL[own];
         const uint8_t* cand;
         bool resolved;
-        if (r < sll) { cand = c.litRle ? c.litBase : c.litBase + c.sLit[own] + r; resolved = true; }
+        uint32_t candLit = 0xFFFFFFFFu;
+        if (r < sll) { candLit = c.sLit[own] + r; cand = c.litRle ? c.litBase : c.litBase + candLit; resolved = true; }
         else {
             uint32_t m = r - sll;
             uint32_t const so = c.sOff[own];
@@ -1153,7 +1156,7 @@ DEVI const uint8_t* resolve_source(const ExecCtx& c, uint32_t k, uint32_t own, b
             resolved = nq < 0;
             if (pending && !resolved) { q = (uint32_t)nq; own = owner_of(c, q); }
         }
-        if (pending && resolved) { ptr = cand; pending = false; }
+        if (pending && resolved) { ptr = cand; litAt = candLit; pending = false; }
     }
     return ptr;
 }
@@ -1219,9 +1222,93 @@ DEVI void copy_long_runs(uint8_t* dst, const uint8_t* src, uint32_t len, bool sp
     }
 }
 
+// One batch copied straight from memory to memory: the path for batches with long runs (literal runs or matches
+// over 32 bytes, or more output than the LDS stage holds).  Kept out of line: it is the rare path.
+__attribute__((noinline)) static __device__ void exec_batch_direct(const uint32_t* sStart, const uint32_t* sLL, const uint32_t* sOff, const uint32_t* sLit,
+                                                                   const uint32_t* sSlowEnd, const uint8_t* litBase, const uint8_t* fdst, const uint8_t* dictEnd,
+                                                                   int64_t batchAbs, bool litRle, uint8_t* myDst, const uint8_t* litSrc, const uint8_t* matSrc,
+                                                                   uint32_t ll, uint32_t fastLen, uint32_t slowTotal, uint8_t* batchDst, uint32_t lane)
+{
+    ExecCtx c;      // (arguments by value: a context passed by reference would live in scratch memory on the caller's hot path too)
+    c.sStart = sStart; c.sLL = sLL; c.sOff = sOff; c.sLit = sLit;
+    c.litBase = litBase; c.fdst = fdst; c.dictEnd = dictEnd;
+    c.batchAbs = batchAbs; c.litRle = litRle;
+    // ---- all loads of the batch ...
+    Run rl, rm;
+    rl.load(litSrc, ll, c.litRle);
+    rm.load(matSrc, fastLen, false);
+    // first pass of the slow bytes: byte j of the concatenated slow matches -> owner by search over the prefix
+    uint32_t sk = 0, la;
+    bool const sAct = lane < slowTotal;
+    const uint8_t* sSrc = c.litBase;
+    if (slowTotal) {
+        uint32_t own = 0;
+#pragma unroll
+        for (int step = 32; step >= 1; step >>= 1) own += (sSlowEnd[own + step - 1] <= lane) ? (uint32_t)step : 0u;
+        own = sAct ? own : 0;
+        uint32_t const mlo = c.sStart[own + 1] - c.sStart[own] - c.sLL[own];
+        sk = c.sStart[own] + c.sLL[own] + (lane - (sSlowEnd[own] - mlo));
+        sSrc = resolve_source(c, sAct ? sk : 0, own, sAct, la);
+    }
+    uint8_t sv = 0;
+    if (slowTotal && sAct) sv = *sSrc;
+    // ---- ... then all stores
+    rl.store(myDst, ll);
+    rm.store(myDst + ll, fastLen);
+    if (slowTotal && sAct) batchDst[sk] = sv;
+    copy_long_runs(myDst, litSrc, ll, c.litRle, lane);
+    copy_long_runs(myDst + ll, matSrc, fastLen, false, lane);
+    // remaining slow bytes, 64 per pass
+    for (uint32_t j0 = 64; j0 < slowTotal; j0 += 64) {
+        uint32_t const j = j0 + lane;
+        bool const act = j < slowTotal;
+        uint32_t own = 0;
+#pragma unroll
+        for (int step = 32; step >= 1; step >>= 1) own += (sSlowEnd[own + step - 1] <= j) ? (uint32_t)step : 0u;
+        own = act ? own : 0;
+        uint32_t const mlo = c.sStart[own + 1] - c.sStart[own] - c.sLL[own];
+        uint32_t const k = c.sStart[own] + c.sLL[own] + (j - (sSlowEnd[own] - mlo));
+        const uint8_t* const sp = resolve_source(c, act ? k : 0, own, act, la);
+        if (act) batchDst[k] = *sp;
+    }
+}
+
+// Two runs of 0..32 bytes each copied inside LDS (unaligned).  A run is two, possibly overlapping, accesses of one
+// size: 16 bytes at the start and 16 at the end for 16..32, likewise 8 / 4 / 2 for shorter runs, one byte for a run
+// of 1 -- an exact cover with at most two accesses.  The two runs go through each size class together.
+template <typename T>
+DEVI void lds_copy_class(uint8_t* dstA, const uint8_t* srcA, uint32_t lenA, uint8_t* dstB, const uint8_t* srcB, uint32_t lenB, uint32_t lo, uint32_t hi)
+{
+    bool const inA = lenA >= lo && lenA < hi, inB = lenB >= lo && lenB < hi;
+    T a0, a1, b0, b1;
+    if (inA) { __builtin_memcpy(&a0, srcA, sizeof(T)); __builtin_memcpy(&a1, srcA + (lenA - sizeof(T)), sizeof(T)); }
+    if (inB) { __builtin_memcpy(&b0, srcB, sizeof(T)); __builtin_memcpy(&b1, srcB + (lenB - sizeof(T)), sizeof(T)); }
+    if (inA) { __builtin_memcpy(dstA, &a0, sizeof(T)); __builtin_memcpy(dstA + (lenA - sizeof(T)), &a1, sizeof(T)); }
+    if (inB) { __builtin_memcpy(dstB, &b0, sizeof(T)); __builtin_memcpy(dstB + (lenB - sizeof(T)), &b1, sizeof(T)); }
+}
+DEVI void lds_copy_runs(uint8_t* dstA, const uint8_t* srcA, uint32_t lenA, uint8_t* dstB, const uint8_t* srcB, uint32_t lenB)
+{
+    lds_copy_class<uint4>(dstA, srcA, lenA, dstB, srcB, lenB, 16, 33);
+    lds_copy_class<uint2>(dstA, srcA, lenA, dstB, srcB, lenB, 8, 16);
+    lds_copy_class<uint32_t>(dstA, srcA, lenA, dstB, srcB, lenB, 4, 8);
+    lds_copy_class<uint16_t>(dstA, srcA, lenA, dstB, srcB, lenB, 2, 4);
+    lds_copy_class<uint8_t>(dstA, srcA, lenA, dstB, srcB, lenB, 1, 2);
+}
+
+// A value known to be the same in every lane, moved to a scalar register.
+DEVI uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+DEVI uint64_t uni(uint64_t v) { return ((uint64_t)uni((uint32_t)(v >> 32)) << 32) | uni((uint32_t)v); }
+DEVI uint32_t lane_value(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+
+constexpr uint32_t kOutStage = 4096;     // output bytes of one batch assembled in LDS
+constexpr uint32_t kLitStage = 1024;     // literal bytes of one batch staged in LDS
+
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_execute(BatchParams p)
 {
     __shared__ uint32_t sStart[65], sLL[64], sOff[64], sLit[64], sSlowEnd[64];
+    __shared__ __attribute__((aligned(16))) uint8_t outStage[kOutStage];
+    __shared__ __attribute__((aligned(16))) uint8_t litStage[kLitStage];
+    __shared__ __attribute__((aligned(16))) uint8_t matStage[64 * 32];      // 32 source bytes per lane
     uint32_t const lane = threadIdx.x;
     uint32_t const fi = blockIdx.x;
     DevFrame const f = p.frames[fi];
@@ -1235,56 +1322,66 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
     uint64_t produced = 0;
 
     for (uint32_t b = f.firstBlock; b < f.firstBlock + f.nBlocks && !ferr; b++) {
-        DevBlock const blk = p.blocks[b];
-        DevBlockState const st = p.state[b];
-        uint64_t const bo = produced;           // block start inside the frame (== st.dstOff)
+        // block descriptor and state are the same for every lane: keep what the loops below use in scalar registers
+        const DevBlock* const bp = p.blocks + b;
+        const DevBlockState* const sp_ = p.state + b;
+        uint32_t const blockType = uni((uint32_t)bp->blockType), origSize = uni(bp->origSize);
+        uint64_t const blkSrcOff = uni(bp->srcOff);
+        uint32_t const hostLitErr = uni((uint32_t)bp->hostLitErr), hostSeqErr = uni((uint32_t)bp->hostSeqErr);
+        uint32_t const litType = uni((uint32_t)bp->litType), nbSeq = uni(bp->nbSeq);
+        uint64_t const bo = produced;           // block start inside the frame (== the layout stage's dstOff)
         uint64_t const room = cap - bo;
-        if (blk.blockType == BT_STOP) { ferr = blk.hostLitErr; break; }
-        if (blk.blockType == BT_RAW) {
-            if (blk.origSize > room) { ferr = E_dstSize_tooSmall; break; }
-            coop_copy(fdst + bo, p.src + blk.srcOff, blk.origSize, lane);
-            produced += blk.origSize;
+        if (blockType == BT_STOP) { ferr = hostLitErr; break; }
+        if (blockType == BT_RAW) {
+            if (origSize > room) { ferr = E_dstSize_tooSmall; break; }
+            coop_copy(fdst + bo, p.src + blkSrcOff, origSize, lane);
+            produced += origSize;
             continue;
         }
-        if (blk.blockType == BT_RLE) {
-            if (blk.origSize > room) { ferr = E_dstSize_tooSmall; break; }
-            uint8_t const v = p.src[blk.srcOff];
-            for (uint64_t i = lane; i < blk.origSize; i += 64) fdst[bo + i] = v;
-            produced += blk.origSize;
+        if (blockType == BT_RLE) {
+            if (origSize > room) { ferr = E_dstSize_tooSmall; break; }
+            uint8_t const v = p.src[blkSrcOff];
+            for (uint64_t i = lane; i < origSize; i += 64) fdst[bo + i] = v;
+            produced += origSize;
             continue;
         }
         // compressed block: error precedence follows ZSTD_decompressBlock_internal (zstd_decompress_block.pas:1491-1542)
-        if (blk.hostLitErr) { ferr = blk.hostLitErr; break; }
-        bool const hufLits = blk.litType >= SET_COMPRESSED;
-        if (hufLits && st.litErr) { ferr = st.litErr; break; }
-        if (blk.hostSeqErr) { ferr = blk.hostSeqErr; break; }
-        if (blk.nbSeq && st.seqErr) { ferr = st.seqErr; break; }
+        if (hostLitErr) { ferr = hostLitErr; break; }
+        bool const hufLits = litType >= SET_COMPRESSED;
+        uint32_t const litErr = uni(sp_->litErr), seqErr = uni(sp_->seqErr), tailErr = uni(sp_->tailErr);
+        if (hufLits && litErr) { ferr = litErr; break; }
+        if (hostSeqErr) { ferr = hostSeqErr; break; }
+        if (nbSeq && seqErr) { ferr = seqErr; break; }
 
-        const uint8_t* const litBase = hufLits ? p.litBuf + blk.litBufOff : p.src + blk.srcOff + blk.litHdrSize;
-        bool const litRle = (blk.litType == SET_RLE);
-        uint32_t const litSize = blk.litSize;
-        uint32_t const nValid = blk.nbSeq ? st.seqValid : 0;
-        const uint4* const recs = (const uint4*)p.seqBuf + blk.seqBufOff;   // nbSeq + 1 records
-        uint32_t const rin0 = st.repIn[0], rin1 = st.repIn[1], rin2 = st.repIn[2];
+        const uint8_t* const litBase = hufLits ? p.litBuf + uni(bp->litBufOff) : p.src + blkSrcOff + uni((uint32_t)bp->litHdrSize);
+        bool const litRle = (litType == SET_RLE);
+        uint32_t const litSize = uni(bp->litSize);
+        uint32_t const rleFill = (litRle && litSize) ? 0x01010101u * uni((uint32_t)litBase[0]) : 0u;
+        uint32_t const nValid = nbSeq ? uni(sp_->seqValid) : 0;
+        const uint4* const recs = (const uint4*)p.seqBuf + uni(bp->seqBufOff);   // nbSeq + 1 records
+        uint32_t const rin0 = uni(sp_->repIn[0]), rin1 = uni(sp_->repIn[1]), rin2 = uni(sp_->repIn[2]);
         uint64_t pos = 0;       // bytes of this block already produced
         uint32_t litPos = 0;
 
         // One sequence per lane: record = (offset, output position, literal position, litLength), block-relative;
         // lanes past the batch's last sequence read the record after it, whose output position ends the batch.
         // The records of the next batch are requested before the stores of the current one.
-        uint4 rcN = make_uint4(0, 0, 0, 0);
-        uint32_t endN = 0;
+        uint4 rcN = make_uint4(0, 0, 0, 0), endN = make_uint4(0, 0, 0, 0);
         if (nValid) {
             uint32_t const n = nValid < 64 ? nValid : 64;
             rcN = recs[lane < n ? lane : n];
-            endN = recs[n].y;
+            endN = recs[n];
         }
         for (uint32_t s0 = 0; s0 < nValid && !ferr; s0 += 64) {
+#ifdef ZG_STAMPS
+            uint64_t const x0 = __builtin_readcyclecounter();
+#endif
             uint32_t const n = nValid - s0 < 64 ? nValid - s0 : 64;
             bool const have = lane < n;
             uint4 const rc = rcN;
+            uint32_t const endY = uni(endN.y), endZ = uni(endN.z);
             uint32_t const below = __shfl_down(rc.y, 1);
-            uint32_t const nstart = lane == 63 ? endN : (have ? below : rc.y);
+            uint32_t const nstart = lane == 63 ? endY : (have ? below : rc.y);
             uint32_t const bstart = rc.y, lstart = rc.z;
             uint32_t const ll = have ? rc.w : 0;
             uint32_t const off = have ? rep_subst(rc.x, rin0, rin1, rin2) : 1;
@@ -1296,26 +1393,35 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
                 else if ((uint64_t)off > bo + bstart + ll + dictN) code = E_corruption;
             }
             unsigned long long const bad = __ballot(code != 0);
-            if (bad) { ferr = __shfl(code, __builtin_ctzll(bad)); break; }
+            if (bad) { ferr = uni((uint32_t)__shfl(code, __builtin_ctzll(bad))); break; }
             uint32_t const ml = nstart - bstart - ll;
-            uint32_t const base0 = __shfl(bstart, 0);                // block-relative start of the batch (== pos)
+            uint32_t const base0 = lane_value(bstart, 0);           // block-relative start of the batch (== pos)
             uint32_t const start = bstart - base0;
-            uint32_t const total = __shfl(nstart, 63) - base0;
+            uint32_t const total = lane_value(nstart, 63) - base0;
             int64_t const batchAbs = (int64_t)(bo + pos);
             // A match is "fast" when its source lies wholly before the batch, on one side of the dictionary
             // boundary, and does not overlap its destination: a plain copy.  Everything else (about 1 match in
             // 12 on text) is resolved byte by byte below.
             int32_t const ms = (int32_t)(start + ll) - (int32_t)off;           // batch-relative source start
             int64_t const absS = batchAbs + ms;
-            bool const fast = have && off >= ml && ms + (int32_t)ml <= 0 && (absS >= 0 || absS + (int64_t)ml <= 0);
+            bool const plain = have && off >= ml && ms + (int32_t)ml <= 0 && (absS >= 0 || absS + (int64_t)ml <= 0);
+            // Batches of short runs (the usual case) are assembled in LDS; there a plain match is fetched as 16 or 32
+            // bytes whatever its length, which must stay inside the frame's output area or the dictionary.
+            uint32_t const lit0 = lane_value(lstart, 0);
+            uint32_t const sumLL = endZ - lit0;          // the literals of a batch are contiguous
+            bool const staged = total <= kOutStage && sumLL <= kLitStage && !__any(ll > 32 || (plain && ml > 32));
+            int64_t const fetchEnd = absS + (ml > 16 ? 32 : 16);
+            bool const fast = plain && (!staged || (absS >= 0 ? fetchEnd <= (int64_t)cap : fetchEnd <= 0));
             uint32_t const fastLen = fast ? ml : 0, slowLen = (have && !fast) ? ml : 0;
             // inclusive prefix of the slow match bytes over the lanes
             uint32_t slowEnd = slowLen;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) { uint32_t const o = __shfl_up(slowEnd, d); if (lane >= (uint32_t)d) slowEnd += o; }
-            uint32_t const slowTotal = __shfl(slowEnd, 63);
+            uint32_t const slowTotal = lane_value(slowEnd, 63);
 
-            wave_sync();      // earlier stores are complete and visible; previous LDS reads done
+            // No wait for the earlier stores: a wave's memory operations are performed in issue order, so the loads
+            // below see every byte this wave has stored.
+            lds_sync();       // previous LDS reads done
             sStart[lane] = start; sLL[lane] = ll; sOff[lane] = off; sLit[lane] = lstart; sSlowEnd[lane] = slowEnd;
             if (lane == 63) sStart[64] = total;
             lds_sync();
@@ -1324,58 +1430,107 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
             c.litBase = litBase; c.fdst = fdst; c.dictEnd = dictEnd;
             c.batchAbs = batchAbs; c.litRle = litRle;
 
+#ifdef ZG_STAMPS
+            uint64_t const x1 = __builtin_readcyclecounter();
+            uint64_t x2 = x1, x3 = x1, x4 = x1;
+#endif
             uint8_t* const myDst = fdst + bo + bstart;
-            const uint8_t* const litSrc = litRle ? litBase : litBase + lstart;
             const uint8_t* const matSrc = absS >= 0 ? fdst + absS : dictEnd + absS;
-            // ---- all loads of the batch ...
-            Run rl, rm;
-            rl.load(litSrc, ll, litRle);
-            rm.load(matSrc, fastLen, false);
-            // first pass of the slow bytes: byte j of the concatenated slow matches -> owner by search over the prefix
-            uint32_t sk = 0;
-            bool sAct = lane < slowTotal;
-            const uint8_t* sSrc = litBase;
-            if (slowTotal) {
-                uint32_t own = 0;
-#pragma unroll
-                for (int step = 32; step >= 1; step >>= 1) own += (sSlowEnd[own + step - 1] <= lane) ? (uint32_t)step : 0u;
-                own = sAct ? own : 0;
-                uint32_t const mlo = sStart[own + 1] - sStart[own] - sLL[own];
-                sk = sStart[own] + sLL[own] + (lane - (sSlowEnd[own] - mlo));
-                sSrc = resolve_source(c, sAct ? sk : 0, own, sAct);
-            }
-            uint8_t sv = 0;
-            if (slowTotal && sAct) sv = *sSrc;
-            if (s0 + 64 < nValid) {
+            if (s0 + 64 < nValid) {     // the next batch's records
                 uint32_t const n2 = nValid - s0 - 64 < 64 ? nValid - s0 - 64 : 64;
                 rcN = recs[s0 + 64 + (lane < n2 ? lane : n2)];
-                endN = recs[s0 + 64 + n2].y;
+                endN = recs[s0 + 64 + n2];
             }
-            // ---- ... then all stores
-            rl.store(myDst, ll);
-            rm.store(myDst + ll, fastLen);
-            if (slowTotal && sAct) fdst[bo + pos + sk] = sv;
-            copy_long_runs(myDst, litSrc, ll, litRle, lane);
-            copy_long_runs(myDst + ll, matSrc, fastLen, false, lane);
-            // remaining slow bytes, 64 per pass
-            for (uint32_t j0 = 64; j0 < slowTotal; j0 += 64) {
-                uint32_t const j = j0 + lane;
-                bool const act = j < slowTotal;
-                uint32_t own = 0;
+            if (staged) {
+                // Small runs (the usual case): assemble the batch's output in LDS and store it with whole-wave
+                // 16-byte stores.  Global accesses per batch: one coalesced literal load, two loads per match with a
+                // source before the batch, single bytes for the matches that depend on the batch itself, and the
+                // output stores.
+                // ---- all global loads of the batch
+                const uint8_t* const litG = litBase + lit0;
+                uint32_t const litFull = sumLL >> 4, litTail = sumLL & 15;
+                uint4 litV = make_uint4(rleFill, rleFill, rleFill, rleFill);
+                uint8_t litT = (uint8_t)rleFill;
+                if (!litRle) {
+                    if (lane < litFull) __builtin_memcpy(&litV, litG + 16 * lane, 16);
+                    if (lane < litTail) litT = litG[16 * litFull + lane];
+                }
+                uint4 mv0 = make_uint4(0, 0, 0, 0), mv1 = mv0;
+                if (fastLen) __builtin_memcpy(&mv0, matSrc, 16);
+                if (fastLen > 16) __builtin_memcpy(&mv1, matSrc + 16, 16);
+                // first pass of the slow bytes: byte j of the concatenated slow matches -> owner by search over the prefix
+                uint32_t sk = 0, sLitAt = 0xFFFFFFFFu;
+                bool const sAct = lane < slowTotal;
+                uint8_t sv = 0;
+                if (slowTotal) {
+                    uint32_t own = 0;
 #pragma unroll
-                for (int step = 32; step >= 1; step >>= 1) own += (sSlowEnd[own + step - 1] <= j) ? (uint32_t)step : 0u;
-                own = act ? own : 0;
-                uint32_t const mlo = sStart[own + 1] - sStart[own] - sLL[own];
-                uint32_t const k = sStart[own] + sLL[own] + (j - (sSlowEnd[own] - mlo));
-                const uint8_t* const sp = resolve_source(c, act ? k : 0, own, act);
-                if (act) fdst[bo + pos + k] = *sp;
+                    for (int step = 32; step >= 1; step >>= 1) own += (sSlowEnd[own + step - 1] <= lane) ? (uint32_t)step : 0u;
+                    own = sAct ? own : 0;
+                    uint32_t const mlo = sStart[own + 1] - sStart[own] - sLL[own];
+                    sk = sStart[own] + sLL[own] + (lane - (sSlowEnd[own] - mlo));
+                    const uint8_t* const sp = resolve_source(c, sAct ? sk : 0, own, sAct, sLitAt);
+                    if (sAct && sLitAt == 0xFFFFFFFFu) sv = *sp;
+                }
+#ifdef ZG_STAMPS
+                x2 = __builtin_readcyclecounter();
+#endif
+                // ---- literals into LDS, then every run into its place in the output stage
+                if (lane < litFull || litRle) *(uint4*)(litStage + 16 * lane) = litV;
+                if (lane < litTail) litStage[16 * litFull + lane] = litT;
+                if (fastLen) *(uint4*)(matStage + 32 * lane) = mv0;
+                if (fastLen > 16) *(uint4*)(matStage + 32 * lane + 16) = mv1;
+#ifdef ZG_STAMPS
+                x3 = __builtin_readcyclecounter();
+#endif
+                lds_sync();
+                lds_copy_runs(outStage + start, litStage + (litRle ? 0u : lstart - lit0), ll, outStage + start + ll, matStage + 32 * lane, fastLen);
+                if (sAct) outStage[sk] = sLitAt == 0xFFFFFFFFu ? sv : litStage[litRle ? 0u : sLitAt - lit0];
+                // remaining slow bytes, 64 per pass
+                for (uint32_t j0 = 64; j0 < slowTotal; j0 += 64) {
+                    uint32_t const j = j0 + lane;
+                    bool const act = j < slowTotal;
+                    uint32_t own = 0;
+#pragma unroll
+                    for (int step = 32; step >= 1; step >>= 1) own += (sSlowEnd[own + step - 1] <= j) ? (uint32_t)step : 0u;
+                    own = act ? own : 0;
+                    uint32_t const mlo = sStart[own + 1] - sStart[own] - sLL[own];
+                    uint32_t const k = sStart[own] + sLL[own] + (j - (sSlowEnd[own] - mlo));
+                    uint32_t la;
+                    const uint8_t* const sp = resolve_source(c, act ? k : 0, own, act, la);
+                    if (act) outStage[k] = la == 0xFFFFFFFFu ? *sp : litStage[litRle ? 0u : la - lit0];
+                }
+                lds_sync();
+                // ---- the batch's output, contiguous: 16 bytes per lane, then the last bytes one per lane
+                {
+                    uint8_t* const d0 = fdst + bo + pos;
+                    uint32_t const full = total >> 4, tail = total & 15;
+                    for (uint32_t u = lane; u < full; u += 64) {
+                        uint4 const x = *(const uint4*)(outStage + 16 * u);
+                        __builtin_memcpy(d0 + 16 * u, &x, 16);
+                    }
+                    if (lane < tail) d0[16 * full + lane] = outStage[16 * full + lane];
+                }
+#ifdef ZG_STAMPS
+                x4 = __builtin_readcyclecounter();
+#endif
+            } else {
+                exec_batch_direct(sStart, sLL, sOff, sLit, sSlowEnd, litBase, fdst, dictEnd, batchAbs, litRle, myDst, litRle ? litBase : litBase + lstart, matSrc,
+                                  ll, fastLen, slowTotal, fdst + bo + pos, lane);
             }
             pos += total;
-            litPos = __shfl(lstart + ll, 63);
+            litPos = lane_value(lstart + ll, 63);
+#ifdef ZG_STAMPS
+            if (p.dbg && lane == 0) {
+                uint64_t const x5 = __builtin_readcyclecounter();
+                uint64_t* const g = p.dbg + 8 * fi;
+                g[0] += x1 - x0; g[1] += x2 - x1; g[2] += x3 - x2; g[3] += x4 - x3; g[4] += x5 - x4; g[5] += 1; g[6] += slowTotal > 64 ? (slowTotal - 1) / 64 : 0; g[7] += staged ? 1 : 0;
+            }
+#endif
         }
         if (ferr) break;
-        if (blk.nbSeq && nValid < blk.nbSeq) { ferr = E_corruption; break; }
-        if (blk.nbSeq && st.tailErr) { ferr = st.tailErr; break; }
+        if (nbSeq && nValid < nbSeq) { ferr = E_corruption; break; }
+        if (nbSeq && tailErr) { ferr = tailErr; break; }
         {   // last literals (:1308-1317)
             uint32_t const rest = litSize - litPos;
             if (pos > room || rest > room - pos) { ferr = E_dstSize_tooSmall; break; }

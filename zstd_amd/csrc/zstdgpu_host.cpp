@@ -548,10 +548,10 @@ extern "C" size_t zstdgpu_batch_decode(zstdgpu_batch* B, const void* devSrc, voi
         hipStreamSynchronize(s);
         std::vector<uint64_t> h((size_t)p.nBlocks * 8);
         hipMemcpy(h.data(), dbgBuf, h.size() * 8, hipMemcpyDeviceToHost);
-        double tb = 0, lp = 0, tot = 0, ns = 0, a = 0, bb = 0, c = 0, d = 0; uint64_t mx = 0; size_t n = 0;
-        for (size_t i = 0; i < p.nBlocks; i++) if (h[8 * i + 2]) { tb += h[8 * i]; lp += h[8 * i + 1]; tot += h[8 * i + 2]; ns += h[8 * i + 3]; a += h[8 * i + 4]; bb += h[8 * i + 5]; c += h[8 * i + 6]; d += h[8 * i + 7]; if (h[8 * i + 2] > mx) mx = h[8 * i + 2]; n++; }
-        if (n) fprintf(stderr, "[stamps] k_sequences per block: tables %.0f  decode loops %.0f  total %.0f (max %llu) ticks; %.0f seqs; %.1f loop ticks/seq; helpers: extract %.0f scan+records %.0f stores+carry %.0f window %.0f\n",
-                       tb / n, lp / n, tot / n, (unsigned long long)mx, ns / n, lp / ns, a / n, bb / n, c / n, d / n);
+        double t[8] = {0}; size_t n = 0;
+        for (size_t i = 0; i < p.nFrames; i++) if (h[8 * i + 5]) { for (int j = 0; j < 8; j++) t[j] += h[8 * i + j]; n++; }
+        if (n) fprintf(stderr, "[stamps] k_execute per frame: setup %.0f  load-issue %.0f  load-wait %.0f  assemble+store %.0f  rest %.0f ticks; %.0f batches, %.0f extra passes, %.0f staged\n",
+                       t[0] / n, t[1] / n, t[2] / n, t[3] / n, t[4] / n, t[5] / n, t[6] / n, t[7] / n);
     }
 #endif
     return hipGetLastError() == hipSuccess ? 0 : mkerr(E_generic);
