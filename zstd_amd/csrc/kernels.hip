@@ -1300,6 +1300,20 @@ DEVI uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane(
 DEVI uint64_t uni(uint64_t v) { return ((uint64_t)uni((uint32_t)(v >> 32)) << 32) | uni((uint32_t)v); }
 DEVI uint32_t lane_value(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
 
+// Cross-lane moves without LDS: DPP row shifts inside rows of 16 lanes and row broadcasts between them.
+template <int CTRL, int ROWMASK>
+DEVI uint32_t dpp_or0(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROWMASK, 0xF, false); }
+// inclusive prefix sum over the 64 lanes of a wave (all lanes active)
+DEVI uint32_t wave_incl_scan(uint32_t v)
+{
+    v += dpp_or0<0x111, 0xF>(v); v += dpp_or0<0x112, 0xF>(v); v += dpp_or0<0x114, 0xF>(v); v += dpp_or0<0x118, 0xF>(v);   // row_shr 1, 2, 4, 8
+    v += dpp_or0<0x142, 0xA>(v);      // lane 15 of rows 0 and 2 onto rows 1 and 3
+    v += dpp_or0<0x143, 0xC>(v);      // lane 31 onto rows 2 and 3
+    return v;
+}
+// value of the next higher lane (own value in lane 63)
+DEVI uint32_t wave_next(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x130, 0xF, 0xF, false); }
+
 constexpr uint32_t kOutStage = 4096;     // output bytes of one batch assembled in LDS
 constexpr uint32_t kLitStage = 1024;     // literal bytes of one batch staged in LDS
 
@@ -1380,7 +1394,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
             bool const have = lane < n;
             uint4 const rc = rcN;
             uint32_t const endY = uni(endN.y), endZ = uni(endN.z);
-            uint32_t const below = __shfl_down(rc.y, 1);
+            uint32_t const below = wave_next(rc.y);
             uint32_t const nstart = lane == 63 ? endY : (have ? below : rc.y);
             uint32_t const bstart = rc.y, lstart = rc.z;
             uint32_t const ll = have ? rc.w : 0;
@@ -1399,53 +1413,38 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
             uint32_t const start = bstart - base0;
             uint32_t const total = lane_value(nstart, 63) - base0;
             int64_t const batchAbs = (int64_t)(bo + pos);
-            // A match is "fast" when its source lies wholly before the batch, on one side of the dictionary
-            // boundary, and does not overlap its destination: a plain copy.  Everything else (about 1 match in
-            // 12 on text) is resolved byte by byte below.
-            int32_t const ms = (int32_t)(start + ll) - (int32_t)off;           // batch-relative source start
+            // A match is "plain" when its source lies wholly before the batch, on one side of the dictionary
+            // boundary, and does not overlap its destination: a copy from memory.  The others (about 1 match in 12 on
+            // text) depend on bytes of the batch itself, or repeat a pattern.
+            int64_t const ms = (int64_t)(start + ll) - (int64_t)off;          // batch-relative source start
             int64_t const absS = batchAbs + ms;
-            bool const plain = have && off >= ml && ms + (int32_t)ml <= 0 && (absS >= 0 || absS + (int64_t)ml <= 0);
+            bool const plain = have && off >= ml && ms + (int64_t)ml <= 0 && (absS >= 0 || absS + (int64_t)ml <= 0);
             // Batches of short runs (the usual case) are assembled in LDS; there a plain match is fetched as 16 or 32
             // bytes whatever its length, which must stay inside the frame's output area or the dictionary.
             uint32_t const lit0 = lane_value(lstart, 0);
             uint32_t const sumLL = endZ - lit0;          // the literals of a batch are contiguous
-            bool const staged = total <= kOutStage && sumLL <= kLitStage && !__any(ll > 32 || (plain && ml > 32));
             int64_t const fetchEnd = absS + (ml > 16 ? 32 : 16);
-            bool const fast = plain && (!staged || (absS >= 0 ? fetchEnd <= (int64_t)cap : fetchEnd <= 0));
-            uint32_t const fastLen = fast ? ml : 0, slowLen = (have && !fast) ? ml : 0;
-            // inclusive prefix of the slow match bytes over the lanes
-            uint32_t slowEnd = slowLen;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { uint32_t const o = __shfl_up(slowEnd, d); if (lane >= (uint32_t)d) slowEnd += o; }
-            uint32_t const slowTotal = lane_value(slowEnd, 63);
-
-            // No wait for the earlier stores: a wave's memory operations are performed in issue order, so the loads
-            // below see every byte this wave has stored.
-            lds_sync();       // previous LDS reads done
-            sStart[lane] = start; sLL[lane] = ll; sOff[lane] = off; sLit[lane] = lstart; sSlowEnd[lane] = slowEnd;
-            if (lane == 63) sStart[64] = total;
-            lds_sync();
-            ExecCtx c;
-            c.sStart = sStart; c.sLL = sLL; c.sOff = sOff; c.sLit = sLit;
-            c.litBase = litBase; c.fdst = fdst; c.dictEnd = dictEnd;
-            c.batchAbs = batchAbs; c.litRle = litRle;
-
+            bool const fastS = plain && (absS >= 0 ? fetchEnd <= (int64_t)cap : fetchEnd <= 0);
+            uint32_t const slowS = (have && !fastS) ? ml : 0;
+            // of a match handled in LDS, the leading bytes whose source lies before the batch come from memory, one per lane
+            int64_t const lead = -ms < (int64_t)(ml < off ? ml : off) ? -ms : (int64_t)(ml < off ? ml : off);
+            uint32_t const gcnt = (slowS && lead > 0) ? (uint32_t)lead : 0u;
+            uint32_t const gEnd = wave_incl_scan(gcnt);
+            bool const staged = total <= kOutStage && sumLL <= kLitStage && lane_value(gEnd, 63) <= 64 && !__any(ll > 32 || (plain && ml > 32));
+            const uint8_t* const matSrc = absS >= 0 ? fdst + absS : dictEnd + absS;
 #ifdef ZG_STAMPS
             uint64_t const x1 = __builtin_readcyclecounter();
             uint64_t x2 = x1, x3 = x1, x4 = x1;
 #endif
-            uint8_t* const myDst = fdst + bo + bstart;
-            const uint8_t* const matSrc = absS >= 0 ? fdst + absS : dictEnd + absS;
             if (s0 + 64 < nValid) {     // the next batch's records
                 uint32_t const n2 = nValid - s0 - 64 < 64 ? nValid - s0 - 64 : 64;
                 rcN = recs[s0 + 64 + (lane < n2 ? lane : n2)];
                 endN = recs[s0 + 64 + n2];
             }
             if (staged) {
-                // Small runs (the usual case): assemble the batch's output in LDS and store it with whole-wave
-                // 16-byte stores.  Global accesses per batch: one coalesced literal load, two loads per match with a
-                // source before the batch, single bytes for the matches that depend on the batch itself, and the
-                // output stores.
+                // Global accesses per batch: one coalesced literal load, one or two 16-byte loads per plain match,
+                // single bytes for source bytes before the batch of the other matches, and the whole-wave output stores.
+                uint32_t const fastLen = fastS ? ml : 0;
                 // ---- all global loads of the batch
                 const uint8_t* const litG = litBase + lit0;
                 uint32_t const litFull = sumLL >> 4, litTail = sumLL & 15;
@@ -1458,24 +1457,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
                 uint4 mv0 = make_uint4(0, 0, 0, 0), mv1 = mv0;
                 if (fastLen) __builtin_memcpy(&mv0, matSrc, 16);
                 if (fastLen > 16) __builtin_memcpy(&mv1, matSrc + 16, 16);
-                // first pass of the slow bytes: byte j of the concatenated slow matches -> owner by search over the prefix
-                uint32_t sk = 0, sLitAt = 0xFFFFFFFFu;
-                bool const sAct = lane < slowTotal;
-                uint8_t sv = 0;
-                if (slowTotal) {
-                    uint32_t own = 0;
-#pragma unroll
-                    for (int step = 32; step >= 1; step >>= 1) own += (sSlowEnd[own + step - 1] <= lane) ? (uint32_t)step : 0u;
-                    own = sAct ? own : 0;
-                    uint32_t const mlo = sStart[own + 1] - sStart[own] - sLL[own];
-                    sk = sStart[own] + sLL[own] + (lane - (sSlowEnd[own] - mlo));
-                    const uint8_t* const sp = resolve_source(c, sAct ? sk : 0, own, sAct, sLitAt);
-                    if (sAct && sLitAt == 0xFFFFFFFFu) sv = *sp;
+                uint32_t gdst = 0xFFFFFFFFu;
+                uint8_t gv = 0;
+                {
+                    const uint8_t* gsrc = fdst;
+                    unsigned long long gm = __ballot(gcnt != 0);
+                    while (gm) {
+                        int const w = __builtin_ctzll(gm);
+                        gm &= gm - 1;
+                        uint32_t const cnt = lane_value(gcnt, w), first = lane_value(gEnd, w) - cnt, d0 = lane_value(start + ll, w);
+                        int64_t const absW = (int64_t)(((uint64_t)lane_value((uint32_t)((uint64_t)absS >> 32), w) << 32) | lane_value((uint32_t)absS, w));
+                        uint32_t const j = lane - first;
+                        if (j < cnt) {
+                            int64_t const abs = absW + j;
+                            gdst = d0 + j;
+                            gsrc = abs >= 0 ? fdst + abs : dictEnd + abs;
+                        }
+                    }
+                    if (gdst != 0xFFFFFFFFu) gv = *gsrc;
                 }
 #ifdef ZG_STAMPS
                 x2 = __builtin_readcyclecounter();
 #endif
-                // ---- literals into LDS, then every run into its place in the output stage
+                // ---- literals and fetched match bytes into LDS, then every run into its place in the output stage
+                lds_sync();       // the previous batch's reads of the stages are done
                 if (lane < litFull || litRle) *(uint4*)(litStage + 16 * lane) = litV;
                 if (lane < litTail) litStage[16 * litFull + lane] = litT;
                 if (fastLen) *(uint4*)(matStage + 32 * lane) = mv0;
@@ -1485,20 +1490,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
 #endif
                 lds_sync();
                 lds_copy_runs(outStage + start, litStage + (litRle ? 0u : lstart - lit0), ll, outStage + start + ll, matStage + 32 * lane, fastLen);
-                if (sAct) outStage[sk] = sLitAt == 0xFFFFFFFFu ? sv : litStage[litRle ? 0u : sLitAt - lit0];
-                // remaining slow bytes, 64 per pass
-                for (uint32_t j0 = 64; j0 < slowTotal; j0 += 64) {
-                    uint32_t const j = j0 + lane;
-                    bool const act = j < slowTotal;
-                    uint32_t own = 0;
-#pragma unroll
-                    for (int step = 32; step >= 1; step >>= 1) own += (sSlowEnd[own + step - 1] <= j) ? (uint32_t)step : 0u;
-                    own = act ? own : 0;
-                    uint32_t const mlo = sStart[own + 1] - sStart[own] - sLL[own];
-                    uint32_t const k = sStart[own] + sLL[own] + (j - (sSlowEnd[own] - mlo));
-                    uint32_t la;
-                    const uint8_t* const sp = resolve_source(c, act ? k : 0, own, act, la);
-                    if (act) outStage[k] = la == 0xFFFFFFFFu ? *sp : litStage[litRle ? 0u : la - lit0];
+                if (gdst != 0xFFFFFFFFu) outStage[gdst] = gv;
+                // ---- the other matches, one after the other in sequence order: everything before a match is in place
+                // when its turn comes.  Byte j repeats pattern byte j mod offset; the pattern is the `offset` bytes before
+                // the match, of which those before the batch were fetched to the head of the match itself.
+                // (LDS operations of a wave execute in order: a read sees the writes issued before it.)
+                {
+                    unsigned long long sm = __ballot(slowS != 0);
+                    while (sm) {
+                        int const w = __builtin_ctzll(sm);
+                        sm &= sm - 1;
+                        uint32_t const d0 = lane_value(start + ll, w), o = lane_value(off, w), m = lane_value(ml, w), g = lane_value(gcnt, w);
+                        if (o < m) {
+                            for (uint32_t j = g + lane; j < m; j += 64) {
+                                uint32_t const q = j % o;
+                                outStage[d0 + j] = outStage[q < g ? d0 + q : d0 - o + q];
+                            }
+                        } else {
+                            for (uint32_t j = g + lane; j < m; j += 64) outStage[d0 + j] = outStage[d0 - o + j];
+                        }
+                    }
                 }
                 lds_sync();
                 // ---- the batch's output, contiguous: 16 bytes per lane, then the last bytes one per lane
@@ -1515,8 +1526,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
                 x4 = __builtin_readcyclecounter();
 #endif
             } else {
-                exec_batch_direct(sStart, sLL, sOff, sLit, sSlowEnd, litBase, fdst, dictEnd, batchAbs, litRle, myDst, litRle ? litBase : litBase + lstart, matSrc,
-                                  ll, fastLen, slowTotal, fdst + bo + pos, lane);
+                // Long runs: straight from memory to memory; the other matches byte by byte through the batch's
+                // sequence table in LDS.
+                uint32_t const fastLen = plain ? ml : 0, slowLen = (have && !plain) ? ml : 0;
+                uint32_t const slowEnd = wave_incl_scan(slowLen);
+                uint32_t const slowTotal = lane_value(slowEnd, 63);
+                lds_sync();       // previous LDS reads done
+                sStart[lane] = start; sLL[lane] = ll; sOff[lane] = off; sLit[lane] = lstart; sSlowEnd[lane] = slowEnd;
+                if (lane == 63) sStart[64] = total;
+                lds_sync();
+                exec_batch_direct(sStart, sLL, sOff, sLit, sSlowEnd, litBase, fdst, dictEnd, batchAbs, litRle, fdst + bo + bstart,
+                                  litRle ? litBase : litBase + lstart, matSrc, ll, fastLen, slowTotal, fdst + bo + pos, lane);
             }
             pos += total;
             litPos = lane_value(lstart + ll, 63);
@@ -1524,7 +1544,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
             if (p.dbg && lane == 0) {
                 uint64_t const x5 = __builtin_readcyclecounter();
                 uint64_t* const g = p.dbg + 8 * fi;
-                g[0] += x1 - x0; g[1] += x2 - x1; g[2] += x3 - x2; g[3] += x4 - x3; g[4] += x5 - x4; g[5] += 1; g[6] += slowTotal > 64 ? (slowTotal - 1) / 64 : 0; g[7] += staged ? 1 : 0;
+                g[0] += x1 - x0; g[1] += x2 - x1; g[2] += x3 - x2; g[3] += x4 - x3; g[4] += x5 - x4; g[5] += 1; g[6] += __builtin_popcountll(__ballot(slowS != 0)); g[7] += staged ? 1 : 0;
             }
 #endif
         }
