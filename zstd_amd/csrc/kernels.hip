@@ -42,6 +42,20 @@ DEVI void lds_sync()
     __builtin_amdgcn_wave_barrier();
 }
 
+// Cross-lane moves without LDS: DPP row shifts inside rows of 16 lanes and row broadcasts between them.
+template <int CTRL, int ROWMASK>
+DEVI uint32_t dpp_or0(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROWMASK, 0xF, false); }
+// inclusive prefix sum over the 64 lanes of a wave (all lanes active)
+DEVI uint32_t wave_incl_scan(uint32_t v)
+{
+    v += dpp_or0<0x111, 0xF>(v); v += dpp_or0<0x112, 0xF>(v); v += dpp_or0<0x114, 0xF>(v); v += dpp_or0<0x118, 0xF>(v);   // row_shr 1, 2, 4, 8
+    v += dpp_or0<0x142, 0xA>(v);      // lane 15 of rows 0 and 2 onto rows 1 and 3
+    v += dpp_or0<0x143, 0xC>(v);      // lane 31 onto rows 2 and 3
+    return v;
+}
+// value of the next higher lane (own value in lane 63)
+DEVI uint32_t wave_next(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x130, 0xF, 0xF, false); }
+
 DEVI uint64_t ld_u64(const uint8_t* p)
 {
     uint64_t v;
@@ -49,7 +63,8 @@ DEVI uint64_t ld_u64(const uint8_t* p)
     return v;
 }
 // little-endian 32-bit read at byte index i of a buffer of `size` bytes, zero beyond the end
-DEVI uint32_t rd32z(const uint8_t* p, uint32_t size, uint32_t i)
+template <typename SrcT>
+DEVI uint32_t rd32z(SrcT p, uint32_t size, uint32_t i)
 {
     uint32_t v = 0;
 #pragma unroll
@@ -133,8 +148,8 @@ DEVI uint4 ld_unit(uintptr_t addr, uintptr_t floor)
 constexpr uint32_t kFail = 0xFFFFFFFFu;
 
 // norm[] receives maxSV+1 entries.  Returns the header size in bytes or kFail.
-template <typename NormPtr>
-DEVI uint32_t dev_readNCount(NormPtr norm, uint32_t& maxSV, uint32_t& tableLog, const uint8_t* src, uint32_t hbSize)
+template <typename NormPtr, typename SrcT>
+DEVI uint32_t dev_readNCount(NormPtr norm, uint32_t& maxSV, uint32_t& tableLog, SrcT src, uint32_t hbSize)
 {
     int const iend = hbSize < 8 ? 8 : (int)hbSize;    // short headers are decoded from a zero-padded copy (:100-113)
     int ip = 0;
@@ -645,6 +660,120 @@ DEVI uint32_t dev_desc_size(int t, uint32_t type, const uint8_t* payload, uint32
     return dev_readNCount(norm, maxSV, tableLog, payload + o, cSize - o);
 }
 
+// Bytes of a table description: the first nStaged of them from a copy in LDS, the rest from memory.
+struct HdrBytes {
+    const uint8_t* lds;
+    const uint8_t* mem;
+    uint32_t nStaged;
+    DEVI uint8_t operator[](uint32_t i) const { return i < nStaged ? lds[i] : mem[i]; }
+};
+
+// What the first lane of a group found for one table: how the 16 lanes fill it.
+enum : uint32_t { TK_FAIL = 0, TK_NORM = 1, TK_RLE = 2, TK_DICT = 3 };
+
+// Description of type `type` -> norm[] (TK_NORM; the table is then built by the group) or a single cell (TK_RLE).
+// ZSTD_buildSeqTable (zstd_decompress_block.pas:626-688) without the repeat arm.  Returns bytes consumed or kFail.
+template <typename CellPtr, typename NormPtr, typename SrcT>
+DEVI uint32_t dev_parse_desc(int t, uint32_t type, SrcT src, uint32_t avail, CellPtr cells, NormPtr norm,
+                             uint32_t& kind, uint32_t& maxSV, uint32_t& log, const uint8_t* llBits, const uint8_t* mlBits)
+{
+    kind = TK_FAIL;
+    if (type == SET_REPEAT) return kFail;   // callers resolve repeat mode to the defining block first
+    if (type == SET_RLE) {
+        if (avail < 1) return kFail;
+        uint32_t const sym = src[0];
+        if (sym > tbl_max(t)) return kFail;
+        cells[0] = seq_cell(t, 0, 0, t == T_LL ? llBits[sym] : t == T_OF ? sym : mlBits[sym], sym);
+        log = 0; kind = TK_RLE;
+        return 1;
+    }
+    if (type == SET_BASIC) {   // predefined distributions (zstd_internal.pas:64-99)
+        if (t == T_LL) { maxSV = 35; log = 6; for (uint32_t s = 0; s <= maxSV; s++) norm[s] = c_LL_defaultNorm[s]; }
+        else if (t == T_OF) { maxSV = 28; log = 5; for (uint32_t s = 0; s <= maxSV; s++) norm[s] = c_OF_defaultNorm[s]; }
+        else { maxSV = 52; log = 6; for (uint32_t s = 0; s <= maxSV; s++) norm[s] = c_ML_defaultNorm[s]; }
+        kind = TK_NORM;
+        return 0;
+    }
+    maxSV = tbl_max(t);
+    uint32_t tableLog = 0;
+    uint32_t const h = dev_readNCount(norm, maxSV, tableLog, src, avail);
+    if (h == kFail) return kFail;
+    if (tableLog > tbl_maxLog(t)) return kFail;
+    log = tableLog; kind = TK_NORM;
+    return h;
+}
+
+// ZSTD_buildFSETable_body (zstd_decompress_block.pas:436-583) by a group of 16 lanes (a DPP row).  The serial
+// algorithm spreads the symbols over the table in steps of `step`, skipping the cells above highThreshold, and
+// then numbers the cells of each symbol in table order.  Here:
+//   1. the first lane lays out the symbols: low-probability ones at the top, a running start for the others;
+//   2. lanes fill occ[r] = symbol of the r-th spread step (by symbol), then each takes a 16th of the step
+//      sequence, counts its unskipped steps, and after a prefix sum over the lanes writes its symbols;
+//   3. each lane counts the symbols in its 16th of the table (rank of every cell inside the chunk), the counts
+//      are prefix-summed per symbol over the lanes, and every cell gets nextState = norm + cells of its symbol
+//      before it.
+// scratch: cum u16[64] | occ u8[512] | cnt u16[16][64]  (2688 bytes)
+constexpr uint32_t kGrpBuildScratch = 128 + 512 + 2048;
+DEVI void grp_build_seq_table(int t, uint32_t* cells, const int16_t* norm, uint32_t maxSV, uint32_t tableLog, uint8_t* scratch, uint32_t gl,
+                              const uint8_t* llBits, const uint8_t* mlBits)
+{
+    uint16_t* const cum = (uint16_t*)scratch;
+    uint8_t* const occ = scratch + 128;
+    uint16_t* const cnt = (uint16_t*)(scratch + 128 + 512);
+    uint32_t const tableSize = 1u << tableLog, mask = tableSize - 1, step = (tableSize >> 1) + (tableSize >> 3) + 3;
+    if (gl == 0) {
+        uint32_t high = tableSize - 1, acc = 0;
+        for (uint32_t s = 0; s <= maxSV; s++) {
+            int const n = norm[s];
+            if (n == -1) cells[high--] = s;
+            else { cum[s] = (uint16_t)acc; acc += (uint32_t)n; }
+        }
+        cum[63] = (uint16_t)high;      // (symbols go up to 52)
+    }
+    lds_sync();
+    uint32_t const high = cum[63];
+    for (uint32_t s = gl; s <= maxSV; s += 16) {
+        int const n = norm[s];
+        uint32_t const c0 = cum[s];
+        for (int i = 0; i < n; i++) occ[c0 + i] = (uint8_t)s;
+    }
+    lds_sync();
+    uint32_t const C = tableSize >> 4, i0 = gl * C;       // tableSize >= 32
+    {
+        uint32_t local = 0;
+        for (uint32_t i = i0; i < i0 + C; i++) local += (((i * step) & mask) <= high) ? 1u : 0u;
+        uint32_t incl = local;
+        incl += dpp_or0<0x111, 0xF>(incl); incl += dpp_or0<0x112, 0xF>(incl); incl += dpp_or0<0x114, 0xF>(incl); incl += dpp_or0<0x118, 0xF>(incl);
+        uint32_t r = incl - local;
+        for (uint32_t i = i0; i < i0 + C; i++) {
+            uint32_t const pos = (i * step) & mask;
+            if (pos <= high) { cells[pos] = occ[r]; r++; }
+        }
+    }
+    for (uint32_t q = 0; q < 8; q++) *(uint4*)(cnt + 64 * gl + 8 * q) = make_uint4(0, 0, 0, 0);
+    lds_sync();
+    for (uint32_t u = i0; u < i0 + C; u++) {
+        uint32_t const sym = cells[u];
+        uint32_t const c = cnt[64 * gl + sym];
+        cnt[64 * gl + sym] = (uint16_t)(c + 1);
+        cells[u] = sym | (c << 8);
+    }
+    lds_sync();
+    for (uint32_t s = gl; s <= maxSV; s += 16) {
+        int const n = norm[s];
+        uint32_t run = n == -1 ? 1u : (uint32_t)n;
+        for (uint32_t l = 0; l < 16; l++) { uint32_t const c = cnt[64 * l + s]; cnt[64 * l + s] = (uint16_t)run; run += c; }
+    }
+    lds_sync();
+    for (uint32_t u = i0; u < i0 + C; u++) {
+        uint32_t const v = cells[u], sym = v & 255u;
+        uint32_t const ns = cnt[64 * gl + sym] + (v >> 8);
+        uint32_t const nb = tableLog - hb32(ns);
+        cells[u] = seq_cell(t, (ns << nb) - tableSize, nb, t == T_LL ? llBits[sym] : t == T_OF ? sym : mlBits[sym], sym);
+    }
+    lds_sync();
+}
+
 // ---------------------------------------------------------------- stage 1: sequences
 // value of the lane D places lower in the same row of 16 lanes (own value where there is none)
 template <int D>
@@ -731,13 +860,15 @@ __global__ __launch_bounds__(kSeqThreads) void k_sequences(BatchParams p)
 {
     __shared__ __attribute__((aligned(16))) uint32_t lds[kSeqJobs * kSeqJobWords];
     __shared__ uint32_t sLLbase[36], sMLbase[53];
+    __shared__ uint8_t sLLbits[36], sMLbits[53];
     __shared__ SeqCtl ctl[kSeqJobs];
     __shared__ uint2 pub[2][kSeqJobs];         // per round parity and block: {cursor after the round, sequences decoded in it}
     __shared__ uint32_t activeFlag[2];         // per round parity: some block still has sequences to decode in that round
     uint32_t const tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    if (tid < 36) sLLbase[tid] = c_LL_base[tid];
-    if (tid < 53) sMLbase[tid] = c_ML_base[tid];
+    if (tid < 36) { sLLbase[tid] = c_LL_base[tid]; sLLbits[tid] = c_LL_bits[tid]; }
+    if (tid < 53) { sMLbase[tid] = c_ML_base[tid]; sMLbits[tid] = c_ML_bits[tid]; }
     if (tid == 0) { activeFlag[0] = 1; activeFlag[1] = 0; }
+    wg_barrier();
 
     // ---------------- helper side set-up (waves 1-4): tables, window, per-block constants
     uint32_t const gl = lane & 15, lead = lane & ~15u;
@@ -763,53 +894,73 @@ __global__ __launch_bounds__(kSeqThreads) void k_sequences(BatchParams p)
         const uint8_t* const payload = p.src + blk.srcOff;
         uint32_t off = blk.seqHdrOff;
         uint32_t logsPacked = 0;
-        if (gl == 0) {
-            int16_t* const norm = (int16_t*)ring0;          // table-building scratch lives where the rings will be
-            uint16_t* const symNext = (uint16_t*)(norm + 64);
-            uint32_t logs[3] = {0, 0, 0};
+        {
+            // scratch while the tables are built: where the window and the rings will be
+            uint8_t* const scr = (uint8_t*)win;
+            uint8_t* const hdr = scr;                              // 256 staged bytes of the table descriptions
+            int16_t* const norm = (int16_t*)(scr + 256);           // 64 counts
+            uint32_t* const note = (uint32_t*)(scr + 384);         // {kind, maxSV, log, consumed} from the first lane
+            uint8_t* const bscr = scr + 512;                       // grp_build_seq_table scratch
+            static_assert(512 + kGrpBuildScratch <= 4 * (4 * (kWinUnits + 1) + 2 * 4 * kSeqRound), "table scratch fits");
+            uint32_t const hdrAvail = off < blk.cSize ? blk.cSize - off : 0;
+            uint32_t const nStaged = hdrAvail < 256 ? hdrAvail : 256;
+            for (uint32_t i = gl; i < nStaged; i += 16) hdr[i] = payload[off + i];
+            lds_sync();
             bool fail = false;
+            uint32_t done = 0;          // description bytes consumed so far
 #pragma unroll
             for (int t = 0; t < 3; t++) {
                 uint32_t const type = t == T_LL ? blk.llType : t == T_OF ? blk.ofType : blk.mlType;
                 int32_t const srcB = t == T_LL ? blk.llSrc : t == T_OF ? blk.ofSrc : blk.mlSrc;
                 uint32_t* const cells = t == T_LL ? tLL : t == T_OF ? tOF : tML;
-                if (fail) break;
-                if (type != SET_REPEAT) {
-                    if (off > blk.cSize) { fail = true; break; }
-                    uint32_t const h = dev_build_from_desc(t, type, payload + off, blk.cSize - off, cells, norm, symNext, logs[t]);
-                    if (h == kFail) { fail = true; break; }
-                    off += h;
-                } else if (srcB == SRC_NONE) {
-                    fail = true;
-                } else if (srcB == SRC_DICT) {
-                    const uint32_t* const dc = t == T_LL ? p.dict->ll : t == T_OF ? p.dict->of : p.dict->ml;
-                    uint32_t const lg = t == T_LL ? p.dict->llLog : t == T_OF ? p.dict->ofLog : p.dict->mlLog;
-                    for (uint32_t u = 0; u < (1u << lg); u++) cells[u] = dc[u];
-                    logs[t] = lg;
-                } else {
-                    // rebuild from the block that defined the table: walk its descriptions up to table t
-                    DevBlock const sb = p.blocks[srcB];
-                    const uint8_t* const sp = p.src + sb.srcOff;
-                    uint32_t o = sb.seqHdrOff;
-                    for (int u = 0; u < t && !fail; u++) {
-                        uint32_t const ut = u == T_LL ? sb.llType : sb.ofType;
-                        uint32_t const sz = dev_desc_size(u, ut, sp, o, sb.cSize, norm);
-                        if (sz == kFail) fail = true; else o += sz;
+                if (gl == 0) {
+                    uint32_t kind = TK_FAIL, maxSV = 0, lg = 0, used = 0;
+                    if (fail) {
+                    } else if (type != SET_REPEAT) {
+                        if (off + done <= blk.cSize) {
+                            HdrBytes hb;
+                            hb.lds = hdr + (done < nStaged ? done : nStaged); hb.mem = payload + off + done; hb.nStaged = done < nStaged ? nStaged - done : 0;
+                            uint32_t const h = dev_parse_desc(t, type, hb, blk.cSize - off - done, cells, norm, kind, maxSV, lg, sLLbits, sMLbits);
+                            if (h != kFail) used = h; else kind = TK_FAIL;
+                        }
+                    } else if (srcB == SRC_DICT) {
+                        kind = TK_DICT;
+                        lg = t == T_LL ? p.dict->llLog : t == T_OF ? p.dict->ofLog : p.dict->mlLog;
+                    } else if (srcB != SRC_NONE) {
+                        // rebuild from the block that defined the table: walk its descriptions up to table t
+                        DevBlock const sb = p.blocks[srcB];
+                        const uint8_t* const sp = p.src + sb.srcOff;
+                        uint32_t o = sb.seqHdrOff;
+                        bool bad = false;
+                        for (int u = 0; u < t && !bad; u++) {
+                            uint32_t const ut = u == T_LL ? sb.llType : sb.ofType;
+                            uint32_t const sz = dev_desc_size(u, ut, sp, o, sb.cSize, norm);
+                            if (sz == kFail) bad = true; else o += sz;
+                        }
+                        if (!bad && o <= sb.cSize) {
+                            uint32_t const stype = t == T_LL ? sb.llType : t == T_OF ? sb.ofType : sb.mlType;
+                            if (dev_parse_desc(t, stype, sp + o, sb.cSize - o, cells, norm, kind, maxSV, lg, sLLbits, sMLbits) == kFail) kind = TK_FAIL;
+                        }
                     }
-                    if (!fail) {
-                        uint32_t const stype = t == T_LL ? sb.llType : t == T_OF ? sb.ofType : sb.mlType;
-                        if (o > sb.cSize || dev_build_from_desc(t, stype, sp + o, sb.cSize - o, cells, norm, symNext, logs[t]) == kFail) fail = true;
-                    }
+                    note[0] = kind; note[1] = maxSV; note[2] = lg; note[3] = used;
                 }
+                lds_sync();
+                uint32_t const kind = note[0], maxSV = note[1], lg = note[2];
+                done += note[3];
+                if (kind == TK_FAIL) fail = true;
+                else if (kind == TK_NORM) grp_build_seq_table(t, cells, norm, maxSV, lg, bscr, gl, sLLbits, sMLbits);
+                else if (kind == TK_DICT) {
+                    const uint32_t* const dc = t == T_LL ? p.dict->ll : t == T_OF ? p.dict->of : p.dict->ml;
+                    for (uint32_t u = gl; u < (1u << lg); u += 16) cells[u] = dc[u];
+                }
+                logsPacked |= lg << (t == T_LL ? 0 : t == T_OF ? 8 : 16);
+                lds_sync();      // the note and the scratch are free again
             }
+            off += done;
             if (!fail && off >= blk.cSize) fail = true;                     // BIT_initDStream on an empty stream
             if (!fail && payload[blk.cSize - 1] == 0) fail = true;          // no end mark
             failU = fail ? 1u : 0u;
-            logsPacked = logs[T_LL] | (logs[T_OF] << 8) | (logs[T_ML] << 16);
         }
-        wave_sync();
-        failU = __shfl(failU, lead);
-        off = __shfl(off, lead);
         if (!failU) {
             const uint8_t* const sStart = payload + off;
             uint32_t const sSize = blk.cSize - off;
@@ -1299,20 +1450,6 @@ DEVI void lds_copy_runs(uint8_t* dstA, const uint8_t* srcA, uint32_t lenA, uint8
 DEVI uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 DEVI uint64_t uni(uint64_t v) { return ((uint64_t)uni((uint32_t)(v >> 32)) << 32) | uni((uint32_t)v); }
 DEVI uint32_t lane_value(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
-
-// Cross-lane moves without LDS: DPP row shifts inside rows of 16 lanes and row broadcasts between them.
-template <int CTRL, int ROWMASK>
-DEVI uint32_t dpp_or0(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROWMASK, 0xF, false); }
-// inclusive prefix sum over the 64 lanes of a wave (all lanes active)
-DEVI uint32_t wave_incl_scan(uint32_t v)
-{
-    v += dpp_or0<0x111, 0xF>(v); v += dpp_or0<0x112, 0xF>(v); v += dpp_or0<0x114, 0xF>(v); v += dpp_or0<0x118, 0xF>(v);   // row_shr 1, 2, 4, 8
-    v += dpp_or0<0x142, 0xA>(v);      // lane 15 of rows 0 and 2 onto rows 1 and 3
-    v += dpp_or0<0x143, 0xC>(v);      // lane 31 onto rows 2 and 3
-    return v;
-}
-// value of the next higher lane (own value in lane 63)
-DEVI uint32_t wave_next(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x130, 0xF, 0xF, false); }
 
 constexpr uint32_t kOutStage = 4096;     // output bytes of one batch assembled in LDS
 constexpr uint32_t kLitStage = 1024;     // literal bytes of one batch staged in LDS
