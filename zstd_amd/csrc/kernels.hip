@@ -1034,6 +1034,9 @@ __global__ __launch_bounds__(kSeqThreads) void k_sequences(BatchParams p)
                     // lowest bit the window is known to hold, plus what 4 sequences and a 96-bit peek can reach
                     uint32_t const Qlim = ((e2 >> 7) - kWinAhead) * 128 + 96 + 4 * 89;
                     uint32_t i = 0;
+                    typedef const __attribute__((address_space(3))) uint32_t* lds_u32;
+                    uint32_t winL = (uint32_t)(uintptr_t)(lds_u32)win;     // LDS byte address of the window, opaque to the compiler:
+                    asm volatile("" : "+v"(winL));                         // keeps the four window reads at small immediate offsets of one address
                     for (; i < kSeqRound; i += 4) {
                         if (Q < Qlim) break;
                         // Past the block's last sequence the chain runs on over bits that mean nothing, inside the window
@@ -1043,7 +1046,7 @@ __global__ __launch_bounds__(kSeqThreads) void k_sequences(BatchParams p)
                         for (uint32_t j = 0; j < 4; j++) {
                             // 96 bits below the cursor (top at Q + 1, so that the state bits of any sequence start inside them)
                             uint32_t const T = Q - 95;
-                            const uint32_t* const w = win + __builtin_amdgcn_ubfe(T, 5, 9);
+                            lds_u32 const w = (lds_u32)(uintptr_t)(winL + 4 * __builtin_amdgcn_ubfe(T, 5, 9));
                             uint32_t const a0 = w[0], a1 = w[1], a2 = w[2], a3 = w[3];
                             uint32_t const cLL = tLL[sLL], cOF = tOF[sOF], cML = tML[sML];
                             uint32_t const t2 = __builtin_amdgcn_alignbit(a3, a2, T), t1 = __builtin_amdgcn_alignbit(a2, a1, T), t0 = __builtin_amdgcn_alignbit(a1, a0, T);
