@@ -342,6 +342,7 @@ constexpr int kHufLanes = 16;                // lanes per literal job: 4 decode 
 constexpr int kHufJobs = 64 / kHufLanes;     // jobs per wave
 constexpr uint32_t kHufTabBytes = 8192;      // 2^12 cells of {byte, nbBits}
 constexpr uint32_t kHufRound = 128;          // symbols per stream per round
+constexpr uint32_t kHufDblLog = 11;          // bits that index the double-symbol cells
 constexpr uint32_t kHufInDw = 96;            // staged input per stream per round (24 units): 128 symbols x <=12 bits + alignment slack
 constexpr uint32_t kHufStageBytes = 4 * 4 * kHufInDw + 4 * kHufRound;   // 4 windows + 4 output stages = 2048
 constexpr uint32_t kHufJobBytes = kHufTabBytes + kHufStageBytes;        // the table-build scratch (weights/pos/rank, 820 B) shares the stage area
@@ -412,11 +413,16 @@ __global__ __launch_bounds__(64) void k_literals(BatchParams p)
     err = __shfl(err, lead); tableLog = __shfl(tableLog, lead); nbSymbols = __shfl(nbSymbols, lead); hSize = __shfl(hSize, lead);
 
     bool ok = (err == 0);
+    // Tables up to 2^11 cells are turned into 2^11 double-symbol cells (4 bytes: two symbols when the codes of both
+    // fit in 11 bits, as HUF_readDTableX2 arranges, huf_decompress.pas:660-760); the single-symbol table they are
+    // derived from sits in the upper half of the table area meanwhile.  A 2^12 table stays single-symbol.
+    bool const dbl = tableLog <= 11;
+    uint16_t* const x1 = dbl ? (uint16_t*)(tab + 4096) : cells;
     if (ok) {
         // table fill (HUF_readDTableX1_wksp second half): cell = {symbol, nbBits = tableLog + 1 - weight}
         if (fromDict) {
             uint32_t const n = 1u << tableLog;
-            for (uint32_t u = sl; u < n; u += kHufLanes) cells[u] = p.dict->huf[u];
+            for (uint32_t u = sl; u < n; u += kHufLanes) x1[u] = p.dict->huf[u];
         } else {
             for (uint32_t n = sl; n < nbSymbols; n += kHufLanes) {
                 uint32_t const w = weights[n];
@@ -424,10 +430,33 @@ __global__ __launch_bounds__(64) void k_literals(BatchParams p)
                     uint32_t const len = (1u << w) >> 1;
                     uint32_t const start = pos[n];
                     uint16_t const cell = (uint16_t)(n | ((tableLog + 1 - w) << 8));
-                    for (uint32_t u = 0; u < len; u++) cells[start + u] = cell;
+                    for (uint32_t u = 0; u < len; u++) x1[start + u] = cell;
                 }
             }
         }
+    }
+    wave_sync();
+    if (ok && dbl) {
+        uint32_t* const x2 = (uint32_t*)tab;
+        uint32_t const up = kHufDblLog - tableLog;
+        // cell i (11 bits of the stream): first symbol from its top bits, second from the bits after the first code if
+        // its whole code is among them
+        //   symbol 1 | symbol 2 << 8 | nbBits of symbol 1 << 16 | nbBits of both (or of the one) << 20 | (two symbols) << 24
+        auto mk = [&](uint32_t i) -> uint32_t {
+            uint32_t const c1 = x1[i >> up], l1 = c1 >> 8;
+            uint32_t const c2 = x1[((i << l1) & ((1u << kHufDblLog) - 1)) >> up], l2 = c2 >> 8;
+            bool const two = l1 + l2 <= kHufDblLog;
+            return (c1 & 0xFF) | (two ? (c2 & 0xFF) << 8 : 0u) | (l1 << 16) | ((two ? l1 + l2 : l1) << 20) | (two ? 1u << 24 : 0u);
+        };
+        // the lower half of the cells does not reach the single-symbol table in the upper half of the area ...
+        for (uint32_t i = sl; i < 1024; i += kHufLanes) x2[i] = mk(i);
+        // ... the upper half does: compute every cell, then overwrite
+        uint32_t e[64];
+#pragma unroll
+        for (int m = 0; m < 64; m++) e[m] = mk(1024 + sl + kHufLanes * m);
+        lds_sync();
+#pragma unroll
+        for (int m = 0; m < 64; m++) x2[1024 + sl + kHufLanes * m] = e[m];
     }
     wave_sync();
 
@@ -498,6 +527,48 @@ __global__ __launch_bounds__(64) void k_literals(BatchParams p)
             const uint32_t* const win = inWin + sl * kHufInDw;
             uint32_t* const so = (uint32_t*)(outStage + sl * kHufRound);
             uint32_t i = 0;
+            if (dbl) {
+                // double-symbol cells: 4 lookups (<= 44 bits, 4..8 symbols) per 64-bit peek.  A lookup writes two bytes;
+                // the second is overwritten by the next lookup when the cell held one symbol.
+                const uint32_t* const x2 = (const uint32_t*)tab;
+                uint8_t* const sb = (uint8_t*)so;
+                uint32_t const o0 = 32 - kHufDblLog;
+                for (; i + 8 <= n;) {
+                    uint32_t tHi, tLo;
+                    peek64(win, Q, tHi, tLo);
+                    uint32_t const c0 = x2[tHi >> o0];
+                    uint32_t o = o0 - __builtin_amdgcn_ubfe(c0, 20, 4);
+                    uint32_t const c1 = x2[__builtin_amdgcn_ubfe(tHi, o, kHufDblLog)];
+                    o -= __builtin_amdgcn_ubfe(c1, 20, 4);
+                    uint32_t const used2 = o0 - o;                       // <= 22
+                    uint32_t const t2 = shl_hi(tHi, tLo, used2);
+                    uint32_t const c2 = x2[t2 >> o0];
+                    uint32_t o2 = o0 - __builtin_amdgcn_ubfe(c2, 20, 4);
+                    uint32_t const c3 = x2[__builtin_amdgcn_ubfe(t2, o2, kHufDblLog)];
+                    o2 -= __builtin_amdgcn_ubfe(c3, 20, 4);
+                    uint16_t const w0 = (uint16_t)c0, w1 = (uint16_t)c1, w2 = (uint16_t)c2, w3 = (uint16_t)c3;
+                    __builtin_memcpy(sb + i, &w0, 2); i += 1 + (c0 >> 24);
+                    __builtin_memcpy(sb + i, &w1, 2); i += 1 + (c1 >> 24);
+                    __builtin_memcpy(sb + i, &w2, 2); i += 1 + (c2 >> 24);
+                    __builtin_memcpy(sb + i, &w3, 2); i += 1 + (c3 >> 24);
+                    Q -= used2 + (o0 - o2);
+                }
+                for (; i + 2 <= n;) {
+                    uint32_t tHi, tLo;
+                    peek64(win, Q, tHi, tLo);
+                    uint32_t const c0 = x2[tHi >> o0];
+                    uint16_t const w0 = (uint16_t)c0;
+                    __builtin_memcpy(sb + i, &w0, 2); i += 1 + (c0 >> 24);
+                    Q -= __builtin_amdgcn_ubfe(c0, 20, 4);
+                }
+                if (i < n) {      // one symbol left: the first of the cell
+                    uint32_t tHi, tLo;
+                    peek64(win, Q, tHi, tLo);
+                    uint32_t const c0 = x2[tHi >> o0];
+                    sb[i] = (uint8_t)c0; i++;
+                    Q -= __builtin_amdgcn_ubfe(c0, 16, 4);
+                }
+            }
             for (; i + 4 <= n; i += 4) {     // 4 symbols (<= 48 bits) per 64-bit peek
                 uint32_t tHi, tLo;
                 peek64(win, Q, tHi, tLo);
