@@ -63,6 +63,47 @@ def records(seed: int, n_records: int, size: int = 4096):
     return out
 
 
+def huf12_frame(seed: int, n: int, single_stream: bool) -> bytes:
+    """A hand-made frame libzstd never produces: one compressed block, literals only (no sequences), Huffman
+    table of the maximum depth the format allows (code lengths 1..12, tableLog 12), direct 4-bit weights."""
+    lens = [2, 2, 2] + list(range(3, 13)) + [12]            # symbol s has a code of lens[s] bits; Kraft sum = 1
+    nsym = len(lens)                                       # (a weight must stay below 12, so no code is shorter than 2 bits)
+    weights = [13 - l for l in lens]                       # weight = tableLog + 1 - nbBits
+    # canonical codes as the decoder's table lays them out: weights ascending, symbols ascending inside a weight
+    order = sorted(range(nsym), key=lambda sym: (weights[sym], sym))
+    code, start = {}, 0
+    for sym in order:
+        w = weights[sym]
+        code[sym] = start >> (w - 1)
+        start += 1 << (w - 1)
+    assert start == 4096
+    rnd = random.Random(seed)
+    data = bytes(rnd.choices(range(nsym), weights=[2.0 ** -l for l in lens], k=n))
+
+    def stream(seg: bytes) -> bytes:
+        acc, nbits = 0, 0
+        for sym in reversed(seg):
+            acc |= code[sym] << nbits
+            nbits += lens[sym]
+        acc |= 1 << nbits                                   # end mark
+        return acc.to_bytes((nbits + 8) // 8, "little")
+
+    listed = weights[:-1] + [0]                             # the last weight is implied; pad to a whole byte
+    desc = bytes([127 + nsym - 1]) + bytes((listed[2 * i] << 4) | listed[2 * i + 1] for i in range(nsym // 2))
+    if single_stream:
+        body = desc + stream(data)
+        assert n < 1024 and len(body) < 1024
+        lit = (2 | (0 << 2) | (n << 4) | (len(body) << 14)).to_bytes(3, "little")
+    else:
+        seg = (n + 3) // 4
+        parts = [stream(data[i * seg:(i + 1) * seg]) for i in range(4)]
+        body = desc + b"".join(struct.pack("<H", len(x)) for x in parts[:3]) + b"".join(parts)
+        lit = (2 | (3 << 2) | (n << 4) | (len(body) << 22)).to_bytes(5, "little")
+    block = lit + body + b"\x00"                           # no sequences
+    hdr = struct.pack("<I", 0xFD2FB528) + bytes([0x60]) + struct.pack("<H", n - 256)    # single segment, 2-byte content size
+    return hdr + (1 | (2 << 1) | (len(block) << 3)).to_bytes(3, "little") + block, data
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     for f in os.listdir(OUT):
@@ -131,6 +172,14 @@ def main():
     for k, n in ((2, 30000), (4, 50000), (16, 100000), (16, 200)):
         add(f"alpha{k}_{n}", z.compress(small_alphabet(k * 1000 + n, n, k), 3), n, note="few/no sequences, Huffman literals")
     add("alpha16_l19", z.compress(small_alphabet(5, 128 * KB, 16), 19, True), 128 * KB, note="Huffman literals level 19")
+
+    # Huffman table of 12 bits (the decoder's limit; encoders stop at 11): hand-made frames, 4 streams and 1 stream
+    fr, plain = huf12_frame(81, 20000, False)
+    out, err = add("huf12_4streams", fr, 20000, note="hand-made: tableLog 12 Huffman literals, 4 streams, no sequences")
+    assert not err and out == plain, (err,)
+    fr, plain = huf12_frame(82, 900, True)
+    out, err = add("huf12_1stream", fr, 900, note="hand-made: tableLog 12 Huffman literals, single stream, no sequences")
+    assert not err and out == plain, (err,)
 
     # ---- sequence-heavy blocks: nbSeq >= 0x7F00 needs the 3-byte count ---------------------------------
     data = many_sequences(21, 128 * KB)
