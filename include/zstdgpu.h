@@ -133,6 +133,8 @@ zstdgpu_batch* zstdgpu_batch_create(zstdgpu_ctx* ctx, const void* hostSrc, size_
 zstdgpu_batch* zstdgpu_batch_create_from_frames(zstdgpu_ctx* ctx, const void* hostSrc, size_t srcBytes,
                                                 const zstdgpu_frame_in* in, uint32_t nFrames,
                                                 const zstdgpu_ddict* ddict);
+/* Destroy a batch before its context.  The two large scratch buffers (literals, sequence records) go back to the
+ * context and are handed to the next batch that fits them, so a steady stream of batches allocates once. */
 void zstdgpu_batch_destroy(zstdgpu_batch* batch);
 
 /* Launch the whole stage chain (literals, sequence decode, layout, sequence execution, XXH64,

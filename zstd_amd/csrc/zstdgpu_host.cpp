@@ -155,6 +155,10 @@ struct zstdgpu_ctx {
     // grow-only device staging for the host-buffer drop-ins
     uint8_t *dSrc = nullptr, *dDst = nullptr;
     size_t dSrcCap = 0, dDstCap = 0;
+    // device buffers of destroyed batches, kept for the next batch (hipMalloc of the hundreds of MB of
+    // literal/sequence scratch costs tens of milliseconds; a steady stream of batches should not pay it again)
+    struct Spare { void* p; size_t bytes; };
+    std::vector<Spare> spare;
 };
 
 struct zstdgpu_ddict {
@@ -172,6 +176,7 @@ struct zstdgpu_batch {
     std::vector<uint32_t> hLitJobs, hSeqJobs;
     DevBlock* dBlocks = nullptr; DevBlockState* dState = nullptr; DevFrame* dFrames = nullptr; DevFrameStatus* dStatus = nullptr;
     uint8_t* dLitBuf = nullptr; uint32_t* dSeqBuf = nullptr; uint32_t *dLitJobs = nullptr, *dSeqJobs = nullptr;
+    size_t litBufBytes = 0, seqBufBytes = 0;      // real sizes of the two big buffers (they return to the context's spare list)
     uint64_t litBytes = 0, nSeqTotal = 0, srcBytes = 0, scratchBytes = 0;
     bool profiling = false;
     hipEvent_t ev[ZSTDGPU_NUM_STAGES + 1] = {};
@@ -190,6 +195,32 @@ bool dalloc(T*& p, size_t n, uint64_t& acct)
     if (hipMalloc((void**)&p, bytes) != hipSuccess) { p = nullptr; return false; }
     acct += bytes;
     return true;
+}
+
+// A batch buffer: a spare one of the context when one fits (at least `bytes`, at most twice that), else a new one.
+// `got` receives the buffer's real size, which goes back to the context with it.
+template <typename T>
+bool balloc(zstdgpu_ctx* ctx, T*& p, size_t n, size_t& got, uint64_t& acct)
+{
+    size_t const bytes = (((n ? n : 1) * sizeof(T)) + 255) & ~(size_t)255;
+    int best = -1;
+    for (size_t i = 0; i < ctx->spare.size(); i++)
+        if (ctx->spare[i].bytes >= bytes && ctx->spare[i].bytes <= 2 * bytes && (best < 0 || ctx->spare[i].bytes < ctx->spare[(size_t)best].bytes)) best = (int)i;
+    if (best >= 0) {
+        p = (T*)ctx->spare[(size_t)best].p; got = ctx->spare[(size_t)best].bytes;
+        ctx->spare.erase(ctx->spare.begin() + best);
+    } else {
+        if (hipMalloc((void**)&p, bytes) != hipSuccess) { p = nullptr; got = 0; return false; }
+        got = bytes;
+    }
+    acct += got;
+    return true;
+}
+void bfree(zstdgpu_ctx* ctx, void* p, size_t bytes)
+{
+    if (!p) return;
+    if (bytes >= (1u << 20) && ctx->spare.size() < 16) ctx->spare.push_back({p, bytes});    // small buffers are cheap to allocate again
+    else hipFree(p);
 }
 
 // Literals-section header (switch of ZSTD_decodeLiteralsBlock, zstd_decompress_block.pas:243-274, :333-400)
@@ -255,7 +286,8 @@ void parse_sections(const uint8_t* payload, DevBlock& d)
 void free_batch_device(zstdgpu_batch* b)
 {
     hipFree(b->dBlocks); hipFree(b->dState); hipFree(b->dFrames); hipFree(b->dStatus);
-    hipFree(b->dLitBuf); hipFree(b->dSeqBuf); hipFree(b->dLitJobs); hipFree(b->dSeqJobs);
+    bfree(b->ctx, b->dLitBuf, b->litBufBytes); bfree(b->ctx, b->dSeqBuf, b->seqBufBytes);
+    hipFree(b->dLitJobs); hipFree(b->dSeqJobs);
     if (b->evReady) for (auto& e : b->ev) hipEventDestroy(e);
 }
 
@@ -300,6 +332,7 @@ extern "C" void zstdgpu_destroy(zstdgpu_ctx* ctx)
     if (!ctx) return;
     set_device(ctx);
     hipFree(ctx->dSrc); hipFree(ctx->dDst);
+    for (auto& sp : ctx->spare) hipFree(sp.p);
     delete ctx;
 }
 
@@ -479,7 +512,7 @@ extern "C" zstdgpu_batch* zstdgpu_batch_create(zstdgpu_ctx* ctx, const void* hos
     B->litBytes = litOff + 64; B->nSeqTotal = seqOff;
     bool ok = dalloc(B->dBlocks, nBlocks, B->scratchBytes) && dalloc(B->dState, nBlocks, B->scratchBytes) &&
               dalloc(B->dFrames, nFrames, B->scratchBytes) && dalloc(B->dStatus, nFrames, B->scratchBytes) &&
-              dalloc(B->dLitBuf, B->litBytes, B->scratchBytes) && dalloc(B->dSeqBuf, seqOff * 4 + 4, B->scratchBytes) &&
+              balloc(ctx, B->dLitBuf, B->litBytes, B->litBufBytes, B->scratchBytes) && balloc(ctx, B->dSeqBuf, seqOff * 4 + 4, B->seqBufBytes, B->scratchBytes) &&
               dalloc(B->dLitJobs, B->hLitJobs.size(), B->scratchBytes) && dalloc(B->dSeqJobs, B->hSeqJobs.size(), B->scratchBytes);
     auto up = [&](void* d, const void* h, size_t n) { return n == 0 || hipMemcpy(d, h, n, hipMemcpyHostToDevice) == hipSuccess; };
     ok = ok && up(B->dBlocks, B->hBlocks.data(), nBlocks * sizeof(DevBlock)) && up(B->dFrames, B->hFrames.data(), nFrames * sizeof(DevFrame)) &&
