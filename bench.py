@@ -156,16 +156,23 @@ def main():
             assert host[o:o + FRAME_BYTES].tobytes() == plain[i]
         del d_plain, host
 
-    # ---- PCIe-inclusive figure (reported aside, never the headline)
+    # ---- PCIe-inclusive figure (reported aside, never the headline): pinned host buffers, H2D + decode + D2H
     e2e = None
     if rank == 0:
-        torch.cuda.synchronize()
-        host_out = np.empty(dst_bytes, dtype=np.uint8)
-        t0 = time.perf_counter()
-        d_src.copy_(torch.from_numpy(src))
-        batch.decode(d_src.data_ptr(), d_dst.data_ptr(), stream)
-        host_out[:] = d_dst.cpu().numpy()
-        e2e = d_bytes / (time.perf_counter() - t0) / 1e9
+        h_src = torch.from_numpy(src).pin_memory()
+        h_out = torch.empty(dst_bytes, dtype=torch.uint8, pin_memory=True)
+        best = None
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            d_src.copy_(h_src, non_blocking=True)
+            batch.decode(d_src.data_ptr(), d_dst.data_ptr(), stream)
+            h_out.copy_(d_dst, non_blocking=True)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            best = dt if best is None or dt < best else best
+        e2e = d_bytes / best / 1e9
+        del h_src, h_out
 
     if rank != 0:
         if dist is not None:
