@@ -849,6 +849,9 @@ DEVI void grp_build_seq_table(int t, uint32_t* cells, const int16_t* norm, uint3
 // value of the lane D places lower in the same row of 16 lanes (own value where there is none)
 template <int D>
 DEVI uint32_t row_up(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x110 + D, 0xF, 0xF, false); }
+// value of lane L of the own quad (4 consecutive lanes)
+template <int L>
+DEVI uint32_t quad_lane(uint32_t x) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, L * 0x55, 0xF, 0xF, true); }
 // lane 15 - i of the row (row_mirror): the first lane of a row receives the last lane's value
 DEVI uint32_t row_last_to_first(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x140, 0xF, 0xF, false); }
 constexpr int kSeqJobs = 16;                // jobs (blocks) per workgroup
@@ -944,9 +947,10 @@ __global__ __launch_bounds__(kSeqThreads) void k_sequences(BatchParams p)
     // ---------------- helper side set-up (waves 1-4): tables, window, per-block constants
     uint32_t const gl = lane & 15, lead = lane & ~15u;
     bool const helper = wave != 0;
-    uint32_t const slot = helper ? (wave - 1) * 4 + (lane >> 4) : (lane & 15);       // block slot inside the workgroup
+    uint32_t const slot = helper ? (wave - 1) * 4 + (lane >> 4) : (lane >> 2);       // block slot inside the workgroup
+    uint32_t const role = lane & 3;            // chain wave: which of a block's four chain lanes this is (LL, ML, OF, cursor)
     uint32_t const job = blockIdx.x * kSeqJobs + slot;
-    bool const hasJob = job < p.nSeqJobs && (helper || lane < 16);
+    bool const hasJob = job < p.nSeqJobs;
     uint32_t* const tLL = lds + slot * kSeqJobWords;
     uint32_t* const tML = tLL + 512;
     uint32_t* const tOF = tML + 512;
@@ -1062,12 +1066,17 @@ __global__ __launch_bounds__(kSeqThreads) void k_sequences(BatchParams p)
     }
     wg_barrier();
 
-    // ---------------- chain side set-up (wave 0, lanes 0-15)
-    uint32_t sLL = 0, sOF = 0, sML = 0;        // FSE states
+    // ---------------- chain side set-up (wave 0): four lanes per block, one per table plus one that records the cursor
+    // (it shadows the offset lane).  Every lane keeps one FSE state; what the lanes need of each other's cells comes
+    // through DPP quad permutes.
+    uint32_t st = 0;                           // this lane's FSE state
     uint32_t Q = 0, e1 = 0, e2 = 0;            // cursor; cursor after the previous round and after the one before
     uint32_t remaining = 0;
     int dryBelow = 0;                          // a cursor below this is past the stream start by more than the last state update may read
-    if (!helper && lane < 16) {
+    typedef const __attribute__((address_space(3))) uint32_t* lds_u32;
+    typedef __attribute__((address_space(3))) uint32_t* lds_u32w;
+    uint32_t const tabL = (uint32_t)(uintptr_t)(lds_u32)(role == 0 ? tLL : role == 1 ? tML : tOF);    // LDS byte address of this lane's table
+    if (!helper) {
         SeqCtl const c = ctl[slot];
         if (!c.fail) {
             remaining = c.nbSeq;
@@ -1077,10 +1086,11 @@ __global__ __launch_bounds__(kSeqThreads) void k_sequences(BatchParams p)
             uint32_t const logLL = c.logs & 255, logOF = (c.logs >> 8) & 255, logML = c.logs >> 16;
             uint32_t tHi, tLo;
             peek64c(win, Q, tHi, tLo);
-            sLL = take(tHi, 0, logLL); sOF = take(tHi, logLL, logOF); sML = take(tHi, logLL + logOF, logML);
+            st = role == 0 ? take(tHi, 0, logLL) : role == 1 ? take(tHi, logLL + logOF, logML) : take(tHi, logLL, logOF);
             Q -= logLL + logOF + logML;
         }
     }
+    uint32_t const maskML = role >= 1 ? 0xFFFFFFFFu : 0u, maskOF = role >= 2 ? 0xFFFFFFFFu : 0u;
 
     // helper-side running state; carried in the group's first lane only: stack after the sequences done so far
     // (relative to the block's incoming stack) and the positions, saturating at 2^31-1 (frames regenerate < 2 GiB,
@@ -1105,9 +1115,9 @@ __global__ __launch_bounds__(kSeqThreads) void k_sequences(BatchParams p)
                     // lowest bit the window is known to hold, plus what 4 sequences and a 96-bit peek can reach
                     uint32_t const Qlim = ((e2 >> 7) - kWinAhead) * 128 + 96 + 4 * 89;
                     uint32_t i = 0;
-                    typedef const __attribute__((address_space(3))) uint32_t* lds_u32;
-                    uint32_t winL = (uint32_t)(uintptr_t)(lds_u32)win;     // LDS byte address of the window, opaque to the compiler:
-                    asm volatile("" : "+v"(winL));                         // keeps the four window reads at small immediate offsets of one address
+                    uint32_t winL = (uint32_t)(uintptr_t)(lds_u32)win;     // LDS byte addresses, opaque to the compiler: keeps the
+                    uint32_t ringL = (uint32_t)(uintptr_t)(lds_u32)ring + 4 * role;    // accesses at small immediate offsets of one address
+                    asm volatile("" : "+v"(winL), "+v"(ringL));
                     for (; i < kSeqRound; i += 4) {
                         if (Q < Qlim) break;
                         // Past the block's last sequence the chain runs on over bits that mean nothing, inside the window
@@ -1119,21 +1129,21 @@ __global__ __launch_bounds__(kSeqThreads) void k_sequences(BatchParams p)
                             uint32_t const T = Q - 95;
                             lds_u32 const w = (lds_u32)(uintptr_t)(winL + 4 * __builtin_amdgcn_ubfe(T, 5, 9));
                             uint32_t const a0 = w[0], a1 = w[1], a2 = w[2], a3 = w[3];
-                            uint32_t const cLL = tLL[sLL], cOF = tOF[sOF], cML = tML[sML];
+                            uint32_t const c = *(lds_u32)(uintptr_t)(tabL + 4 * st);
                             uint32_t const t2 = __builtin_amdgcn_alignbit(a3, a2, T), t1 = __builtin_amdgcn_alignbit(a2, a1, T), t0 = __builtin_amdgcn_alignbit(a1, a0, T);
-                            uint32_t const S = cLL + cML + cOF;
+                            // sum of the block's three cells: bit counts of the sequence
+                            uint32_t const S = quad_lane<0>(c) + quad_lane<1>(c) + quad_lane<2>(c);
                             uint32_t const nEx = __builtin_amdgcn_ubfe(S, 19, 6);
                             // the 32 bits under the additional bits: bit 63 - nEx of (t2:t1:t0) upwards
                             uint32_t const R = 63u - nEx;
                             bool const up = R >= 32u;
                             uint32_t const h3 = __builtin_amdgcn_alignbit(up ? t2 : t1, up ? t1 : t0, R);
-                            *(uint4*)(ring + 4 * (i + j)) = make_uint4(cLL, cML, cOF, Q);
-                            // state update, order LL, ML, OF (:1220-1225); a cell's nextState has its low nbBits clear
-                            uint32_t const n4 = cell_nbBits(cLL), n5 = cell_nbBits(cML), n6 = cell_nbBits(cOF);
-                            uint32_t const o4 = 32u - n4, o5 = o4 - n5, o6 = o5 - n6;
-                            sLL = (cLL & 0x1FF) | __builtin_amdgcn_ubfe(h3, o4, n4);
-                            sML = (cML & 0x1FF) | __builtin_amdgcn_ubfe(h3, o5, n5);
-                            sOF = (cOF & 0x1FF) | __builtin_amdgcn_ubfe(h3, o6, n6);
+                            *(lds_u32w)(uintptr_t)(ringL + 16 * (i + j)) = role == 3 ? Q : c;
+                            // state update, order LL, ML, OF (:1220-1225): this lane's bits lie under those of the tables before it;
+                            // a cell's nextState has its low nbBits clear
+                            uint32_t const n = cell_nbBits(c);
+                            uint32_t const o = 32u - (quad_lane<0>(n) + (quad_lane<1>(n) & maskML) + (n & maskOF));
+                            st = (c & 0x1FF) | __builtin_amdgcn_ubfe(h3, o, n);
                             Q -= __builtin_amdgcn_ubfe(S, 12, 7);
                         }
                     }
@@ -1144,7 +1154,7 @@ __global__ __launch_bounds__(kSeqThreads) void k_sequences(BatchParams p)
                     if ((int)Q < dryBelow) remaining = 0;
                     e2 = e1; e1 = Q;
                 }
-                if (lane < 16) pub[par][lane] = make_uint2(Q, n);
+                if (role == 0) pub[par][slot] = make_uint2(Q, n);
                 bool const anyLeft = __any(remaining != 0);
                 if (lane == 0) activeFlag[par ^ 1] = anyLeft ? 1u : 0u;
             }
