@@ -342,7 +342,10 @@ constexpr int kHufLanes = 16;                // lanes per literal job: 4 decode 
 constexpr int kHufJobs = 64 / kHufLanes;     // jobs per wave
 constexpr uint32_t kHufTabBytes = 8192;      // 2^12 cells of {byte, nbBits}
 constexpr uint32_t kHufRound = 128;          // symbols per stream per round
-constexpr uint32_t kHufDblLog = 11;          // bits that index the double-symbol cells
+constexpr uint32_t kPackTabEntries = 17;    // per literal job: 16 parts + a flag
+constexpr uint32_t kSpecZone = 2048;        // split decode: bits in which neighbouring parts look for a common code boundary
+constexpr uint32_t kSpecRound = 32;         // split decode: symbols per lane per round
+constexpr uint32_t kSpecWinDw = 24;         // split decode: staged input per lane (6 units): 32 symbols x <= 12 bits + alignment slack
 constexpr uint32_t kHufInDw = 96;            // staged input per stream per round (24 units): 128 symbols x <=12 bits + alignment slack
 constexpr uint32_t kHufStageBytes = 4 * 4 * kHufInDw + 4 * kHufRound;   // 4 windows + 4 output stages = 2048
 constexpr uint32_t kHufJobBytes = kHufTabBytes + kHufStageBytes;        // the table-build scratch (weights/pos/rank, 820 B) shares the stage area
@@ -375,7 +378,7 @@ DEVI void huf_flush(uint8_t* out, const uint8_t* outStage, const HufGeo& g, uint
     }
 }
 
-__global__ __launch_bounds__(64) void k_literals(BatchParams p)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_literals(BatchParams p)
 {
     __shared__ __attribute__((aligned(16))) uint8_t lds[kHufJobs * kHufJobBytes];
     uint32_t const lane = threadIdx.x;
@@ -392,15 +395,30 @@ __global__ __launch_bounds__(64) void k_literals(BatchParams p)
     uint32_t* const inWin = (uint32_t*)(tab + kHufTabBytes);          // [4][kHufInDw] dwords
     uint8_t* const outStage = tab + kHufTabBytes + 4 * 4 * kHufInDw;  // [4][kHufRound] bytes
 
+#ifdef ZG_STAMPS
+    uint64_t const y0 = __builtin_readcyclecounter();
+    uint64_t yA = 0, yB = 0, yC = 0, yD = 0, yN = 0, yS = 0;
+#endif
     uint32_t err = 0, tableLog = 0, nbSymbols = 0, hSize = 0;
     bool const fromDict = (blk.hufSrc == SRC_DICT);
+    // The table description (at most 129 bytes) is parsed by one lane; the group first copies it into LDS, with the
+    // 8 bytes before it that the backward bit reader may touch (block and literals headers always precede it).
+    uint8_t* const hdrStage = tab + 2048;
+    uint32_t descAvail = 0;
+    if (blk.hufSrc >= 0) {
+        DevBlock const sb = (blk.hufSrc == (int32_t)b) ? blk : p.blocks[blk.hufSrc];
+        const uint8_t* const dp = p.src + sb.srcOff + sb.litHdrSize;
+        descAvail = sb.litCSize < 136 ? sb.litCSize : 136;
+        for (uint32_t i = sl; i < descAvail + 8; i += kHufLanes) hdrStage[i] = dp[(int)i - 8];
+    }
+    lds_sync();
     if (sl == 0) {
         if (blk.litType == SET_COMPRESSED && !blk.singleStream && (blk.litSize == 0 || blk.litCSize == 0)) err = E_corruption;   // huf_decompress.pas:1421-1424
         else if (blk.hufSrc == SRC_NONE) err = E_corruption;
         else if (fromDict) tableLog = p.dict->hufLog;
         else {
             DevBlock const sb = (blk.hufSrc == (int32_t)b) ? blk : p.blocks[blk.hufSrc];
-            uint32_t const r = dev_huf_read_table_desc(p.src + sb.srcOff + sb.litHdrSize, sb.litCSize, weights, pos, rank, tab, nbSymbols, tableLog);
+            uint32_t const r = dev_huf_read_table_desc(hdrStage + 8, sb.litCSize, weights, pos, rank, tab, nbSymbols, tableLog);
             if (r == kFail) err = E_corruption;
             else {
                 hSize = r;
@@ -409,15 +427,14 @@ __global__ __launch_bounds__(64) void k_literals(BatchParams p)
         }
     }
     wave_sync();
+#ifdef ZG_STAMPS
+    uint64_t const yp = __builtin_readcyclecounter();
+#endif
     uint32_t const lead = sub * kHufLanes;
     err = __shfl(err, lead); tableLog = __shfl(tableLog, lead); nbSymbols = __shfl(nbSymbols, lead); hSize = __shfl(hSize, lead);
 
     bool ok = (err == 0);
-    // Tables up to 2^11 cells are turned into 2^11 double-symbol cells (4 bytes: two symbols when the codes of both
-    // fit in 11 bits, as HUF_readDTableX2 arranges, huf_decompress.pas:660-760); the single-symbol table they are
-    // derived from sits in the upper half of the table area meanwhile.  A 2^12 table stays single-symbol.
-    bool const dbl = tableLog <= 11;
-    uint16_t* const x1 = dbl ? (uint16_t*)(tab + 4096) : cells;
+    uint16_t* const x1 = cells;
     if (ok) {
         // table fill (HUF_readDTableX1_wksp second half): cell = {symbol, nbBits = tableLog + 1 - weight}
         if (fromDict) {
@@ -436,30 +453,14 @@ __global__ __launch_bounds__(64) void k_literals(BatchParams p)
         }
     }
     wave_sync();
-    if (ok && dbl) {
-        uint32_t* const x2 = (uint32_t*)tab;
-        uint32_t const up = kHufDblLog - tableLog;
-        // cell i (11 bits of the stream): first symbol from its top bits, second from the bits after the first code if
-        // its whole code is among them
-        //   symbol 1 | symbol 2 << 8 | nbBits of symbol 1 << 16 | nbBits of both (or of the one) << 20 | (two symbols) << 24
-        auto mk = [&](uint32_t i) -> uint32_t {
-            uint32_t const c1 = x1[i >> up], l1 = c1 >> 8;
-            uint32_t const c2 = x1[((i << l1) & ((1u << kHufDblLog) - 1)) >> up], l2 = c2 >> 8;
-            bool const two = l1 + l2 <= kHufDblLog;
-            return (c1 & 0xFF) | (two ? (c2 & 0xFF) << 8 : 0u) | (l1 << 16) | ((two ? l1 + l2 : l1) << 20) | (two ? 1u << 24 : 0u);
-        };
-        // the lower half of the cells does not reach the single-symbol table in the upper half of the area ...
-        for (uint32_t i = sl; i < 1024; i += kHufLanes) x2[i] = mk(i);
-        // ... the upper half does: compute every cell, then overwrite
-        uint32_t e[64];
-#pragma unroll
-        for (int m = 0; m < 64; m++) e[m] = mk(1024 + sl + kHufLanes * m);
-        lds_sync();
-#pragma unroll
-        for (int m = 0; m < 64; m++) x2[1024 + sl + kHufLanes * m] = e[m];
-    }
+#ifdef ZG_STAMPS
+    uint64_t const yf = __builtin_readcyclecounter();
+#endif
     wave_sync();
 
+#ifdef ZG_STAMPS
+    uint64_t const y1 = __builtin_readcyclecounter();
+#endif
     // ---- stream geometry, known to every lane of the group (huf_decompress.pas:406-421)
     uint32_t const tabHdr = (blk.litType == SET_COMPRESSED) ? hSize : 0;
     const uint8_t* const cs = p.src + blk.srcOff + blk.litHdrSize + tabHdr;
@@ -496,28 +497,265 @@ __global__ __launch_bounds__(64) void k_literals(BatchParams p)
     uintptr_t const floorAddr = (uintptr_t)p.src;
     uint32_t const shift = 32 - tableLog;
     uint32_t done = 0;                            // symbols of my stream already decoded
-    for (uint32_t r0 = 0; r0 < maxCnt; r0 += kHufRound) {
-        // 1. stage: 4 windows x 24 aligned 16-byte units, 6 per lane
-        uintptr_t wb[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            int const bl = __shfl(bitsLeft, lead + k);
-            uintptr_t const top = (uintptr_t)(cs + g.sOff(k)) + (uintptr_t)((bl > 0 ? bl + 7 : 0) >> 3);
-            wb[k] = ((top + 15) & ~(uintptr_t)15) - 4 * kHufInDw;
+    // ---- split decode: four lanes per stream.
+    // A Huffman stream can only be decoded from its first code, but a decoder started at an arbitrary bit falls into
+    // step with the true code boundaries after a few symbols.  Lane (stream k, part j) starts at bit j/4 of the stream
+    // and decodes into a scratch region of its own.  While it is in the first kSpecZone bits of its part it marks the
+    // code boundaries it visits in a bitmap (LDS).  When it reaches the next part it looks its own boundaries up in
+    // that part's bitmap: at the first one found there the two decoders have met, the next part is on the true path
+    // from there on (part 0 is from its start), and this lane stops.  A lane that crosses the whole zone without
+    // meeting the next part carries on through that part (whose own output is then dropped) towards the part after
+    // it.  Popcounts of the bitmaps tell how many symbols of a part came before it was on the true path; a final copy
+    // packs the parts into the literal buffer.  If the totals disagree with the stream's symbol count, or a scratch
+    // region overflows, the block is decoded again stream by stream below (which also yields the verdict for corrupt
+    // streams).
+    bool specDone = false;
+    {
+        uint32_t const k = sl & 3, j = sl >> 2;
+        int T = 0;
+        bool sbad = !ok || nStreams != 4 || p.litTmp == nullptr || mySize == 0 || tableLog > 11;    // (a 2^12 table leaves no LDS for the bitmaps)
+        if (!sbad) {
+            uint32_t const last = myStart[mySize - 1];
+            if (last == 0) sbad = true;
+            else T = (int)(mySize * 8) - (int)(8 - hb32(last));
         }
+        if (T < (int)(4 * (2 * kSpecZone + 64))) sbad = true;       // parts long enough that the zones stay apart
+        bool const eligible = ((__ballot(sbad) >> lead) & 0xFFFFu) == 0;
+        if (eligible) {
+            constexpr uint32_t kMapDw = kSpecZone / 32;
+            static_assert(16 * 4 * kMapDw <= 4096, "bitmaps fit in the upper half of the table area");
+            uint32_t* const maps = (uint32_t*)(tab + 4096);            // [16 lanes][kMapDw]
+            uint32_t* const hbm = maps + sl * kMapDw;
+            for (uint32_t q = 0; q < kMapDw; q += 4) *(uint4*)(hbm + q) = make_uint4(0, 0, 0, 0);
+            auto boundary = [&](uint32_t t) -> int { return T - (int)((t * (uint32_t)T) >> 2); };     // first bit of part t (0 for t = 4)
+            int const Bj = boundary(j);
+            uint32_t t = j + 1;             // the part this lane is heading for (4: the end of the stream)
+            int Bt = boundary(t);
+            int cur = Bj;
+            uint32_t nDec = 0;              // symbols decoded by this lane
+            bool met = false, failed = false;
+            uint32_t upTo = 0, meetBit = 0; // symbols before the meeting point; its bit in the target's map
+            uint32_t const laneCap = litTmpLane(blk.litSize);
+            uint8_t* const tmpL = p.litTmp + blk.litTmpOff + (size_t)sl * laneCap;
+            uint32_t* const winL = inWin + sl * kSpecWinDw;
+            uint32_t* const soL = (uint32_t*)(outStage + sl * kSpecRound);
+            uintptr_t wbL = 0;
+            bool prevActive = false;
+#ifdef ZG_STAMPS
+            uint64_t zA = 0, zB = 0, zC = 0, zR = 0, zS = 0, zG = 0, zZ = 0; uint64_t const z0 = __builtin_readcyclecounter();
+#endif
+            for (uint32_t r = 0;; r++) {
+#ifdef ZG_STAMPS
+                uint64_t const za = __builtin_readcyclecounter();
+#endif
+                bool const active = !met && !failed;
+                bool const anyActive = ((__ballot(active) >> lead) & 0xFFFFu) != 0;
+                // window of this lane: 6 aligned units ending just above its unread bits; loaded again when it runs low
+                bool const low = active && (r == 0 || (int)(8 * (int64_t)((uintptr_t)myStart - wbL)) + cur < (int)(12 * kSpecRound + 96));
+                bool const stage = anyActive && ((__ballot(low) >> lead) & 0xFFFFu) != 0;
+                uint4 v[6];
+                if (stage) {
+                    uintptr_t const top = (uintptr_t)myStart + (uintptr_t)((cur > 0 ? cur + 7 : 0) >> 3);
+                    wbL = ((top + 15) & ~(uintptr_t)15) - 4 * kSpecWinDw;
+#pragma unroll
+                    for (int q = 0; q < 6; q++) v[q] = ld_unit(wbL + 16 * q, floorAddr);
+                }
+                // the previous round's bytes go to the lane's scratch region
+                if (prevActive) {
+                    uint4 const x0 = *(const uint4*)soL, x1v = *(const uint4*)(soL + 4);
+                    __builtin_memcpy(tmpL + kSpecRound * (r - 1), &x0, 16);
+                    __builtin_memcpy(tmpL + kSpecRound * (r - 1) + 16, &x1v, 16);
+                }
+                if (!anyActive) break;
+#ifdef ZG_STAMPS
+                uint64_t const zb = __builtin_readcyclecounter();
+#endif
+                lds_sync();
+                if (stage) {
+#pragma unroll
+                    for (int q = 0; q < 6; q++) *(uint4*)(winL + 4 * q) = v[q];
+                }
+                lds_sync();
+#ifdef ZG_STAMPS
+                uint64_t const zc = __builtin_readcyclecounter();
+                zA += zb - za; zB += zc - zb; zR += 1; zS += stage ? 1 : 0;
+#endif
+                prevActive = false;
+                if (active) {
+                    if (kSpecRound * (r + 1) > laneCap) failed = true;
+                    else {
+                        prevActive = true;
+                        int const Qbase = (int)(8 * (int64_t)((uintptr_t)myStart - wbL));
+                        // always the whole round (no lane-dependent exit from the loop): a lane that has met the part ahead, or
+                        // failed, decodes on harmlessly inside its window; what it produces past that point is never used
+#pragma unroll
+                        for (uint32_t gq = 0; gq < kSpecRound / 4; gq++) {
+                            uint32_t const Q = (uint32_t)(Qbase + cur);
+                            uint32_t tHi, tLo;
+                            peek64(winL, Q, tHi, tLo);
+                            uint32_t const c0 = cells[tHi >> shift];
+                            uint32_t const l0 = c0 >> 8;
+                            uint32_t const c1 = cells[shl_hi(tHi, tLo, l0) >> shift];
+                            uint32_t const l1 = l0 + (c1 >> 8);
+                            uint32_t const c2 = cells[shl_hi(tHi, tLo, l1) >> shift];
+                            uint32_t const l2 = l1 + (c2 >> 8);
+                            uint32_t const c3 = cells[shl_hi(tHi, tLo, l2) >> shift];
+                            uint32_t const l3 = l2 + (c3 >> 8);
+                            soL[gq] = (c0 & 0xFF) | ((c1 & 0xFF) << 8) | ((c2 & 0xFF) << 16) | (c3 << 24);
+                            // code boundaries of the four symbols: cur, cur - l0, cur - l1, cur - l2
+                            int const cb0 = cur, cb1 = cur - (int)l0, cb2 = cur - (int)l1, cb3 = cur - (int)l2;
+                            if (__any(cur + (int)kSpecZone > Bj)) {
+                                // own zone: mark the boundaries (a boundary outside the zone ORs nothing into the map's first word)
+                                uint32_t const h0 = (uint32_t)(Bj - cb0), h1 = (uint32_t)(Bj - cb1), h2 = (uint32_t)(Bj - cb2), h3 = (uint32_t)(Bj - cb3);
+                                atomicOr(hbm + (h0 < kSpecZone ? h0 >> 5 : 0u), h0 < kSpecZone ? 1u << (h0 & 31) : 0u);
+                                atomicOr(hbm + (h1 < kSpecZone ? h1 >> 5 : 0u), h1 < kSpecZone ? 1u << (h1 & 31) : 0u);
+                                atomicOr(hbm + (h2 < kSpecZone ? h2 >> 5 : 0u), h2 < kSpecZone ? 1u << (h2 & 31) : 0u);
+                                atomicOr(hbm + (h3 < kSpecZone ? h3 >> 5 : 0u), h3 < kSpecZone ? 1u << (h3 & 31) : 0u);
+                            }
+                            if (__any(cur - 48 <= Bt)) {
+                                // the zone of the part ahead: is one of the boundaries marked there?  (the end of the stream: is one of them bit 0?)
+                                const uint32_t* const tmap = maps + (k + 4 * (t < 4 ? t : 0u)) * kMapDw;
+                                uint32_t const b0 = (uint32_t)(Bt - cb0), b1 = (uint32_t)(Bt - cb1), b2 = (uint32_t)(Bt - cb2), b3 = (uint32_t)(Bt - cb3);
+                                uint32_t const w0 = tmap[b0 < kSpecZone ? b0 >> 5 : 0u], w1 = tmap[b1 < kSpecZone ? b1 >> 5 : 0u],
+                                               w2 = tmap[b2 < kSpecZone ? b2 >> 5 : 0u], w3 = tmap[b3 < kSpecZone ? b3 >> 5 : 0u];
+                                bool const last = t == 4;
+                                bool const x0 = last ? cb0 == 0 : (b0 < kSpecZone && ((w0 >> (b0 & 31)) & 1u));
+                                bool const x1 = last ? cb1 == 0 : (b1 < kSpecZone && ((w1 >> (b1 & 31)) & 1u));
+                                bool const x2 = last ? cb2 == 0 : (b2 < kSpecZone && ((w2 >> (b2 & 31)) & 1u));
+                                bool const x3 = last ? cb3 == 0 : (b3 < kSpecZone && ((w3 >> (b3 & 31)) & 1u));
+                                if ((x0 | x1 | x2 | x3) && !met && !failed) {
+                                    met = true;
+                                    upTo = nDec + (x0 ? 0u : x1 ? 1u : x2 ? 2u : 3u);
+                                    meetBit = x0 ? b0 : x1 ? b1 : x2 ? b2 : b3;
+                                }
+                            }
+                            nDec += 4;
+                            cur -= (int)l3;
+                            {
+                                bool const open = !met && !failed;
+                                bool const atEnd = open && t == 4;
+                                if (atEnd && cur == 0) { met = true; upTo = nDec; }
+                                if (atEnd && cur < 0) failed = true;
+                                bool const carryOn = open && t < 4 && cur <= Bt - (int)kSpecZone;      // crossed the zone without meeting: on through that part
+                                t += carryOn ? 1u : 0u;
+                                Bt = boundary(t);
+                            }
+                        }
+                    }
+                }
+                lds_sync();
+#ifdef ZG_STAMPS
+                zC += __builtin_readcyclecounter() - zc;
+#endif
+            }
+#ifdef ZG_STAMPS
+            uint64_t const z1 = __builtin_readcyclecounter();
+#endif
+            // ---- what every lane found: {target part, symbols before the meeting point, symbols the target decoded before it, ok}
+            uint32_t headOfTarget = 0;
+            if (met && t < 4) {
+                const uint32_t* const tmap = maps + (k + 4 * t) * kMapDw;
+                for (uint32_t w = 0; w <= (meetBit >> 5); w++) {
+                    uint32_t const word = tmap[w];
+                    headOfTarget += __builtin_popcount(w < (meetBit >> 5) ? word : word & ((1u << (meetBit & 31)) - 1u));
+                }
+            }
+            lds_sync();
+            uint4* const recs = (uint4*)outStage;       // [16 lanes], the output stages are free now
+            recs[sl] = make_uint4(t, upTo, headOfTarget, (met && !failed) ? 1u : 0u);
+            lds_sync();
+            // walk the stream's parts along the true path: part 0, then the part it met, and so on to the end
+            uint32_t val0 = 0, val1 = 0, val2 = 0, val3 = 0, hd0 = 0, hd1 = 0, hd2 = 0, hd3 = 0;
+            bool chainOk = true;
+            {
+                uint32_t part = 0, head = 0;
+#pragma unroll
+                for (int step = 0; step < 4; step++) {
+                    if (part < 4) {
+                        uint4 const rc = recs[k + 4 * part];
+                        uint32_t const vv = rc.y - head;
+                        if (!rc.w || rc.y < head || rc.y > laneCap) chainOk = false;
+                        if (part == 0) { val0 = vv; hd0 = head; } else if (part == 1) { val1 = vv; hd1 = head; } else if (part == 2) { val2 = vv; hd2 = head; } else { val3 = vv; hd3 = head; }
+                        head = rc.z;
+                        part = rc.x;
+                    }
+                }
+                if (part != 4) chainOk = false;
+            }
+            bool const lbad = !chainOk || val0 + val1 + val2 + val3 != myCnt;
+            specDone = ((__ballot(lbad) >> lead) & 0xFFFFu) == 0;
+#ifdef ZG_STAMPS
+            if (p.dbg) {
+                uint64_t* const q = p.dbg + 16 * (size_t)p.nBlocks + 16 * (size_t)b;
+                atomicOr((unsigned long long*)&q[12], (unsigned long long)(64u | (failed ? 1u : 0u) | (!chainOk ? 2u : 0u) | (lbad ? 4u : 0u) | (t != j + 1 ? 8u : 0u)));
+                if (sl == 0) { q[1] = zA; q[2] = zB; q[3] = zC; q[4] = z1 - z0; }
+            }
+#endif
+#ifdef ZG_STAMPS
+            uint64_t const z2 = __builtin_readcyclecounter();
+#endif
+            if (specDone) {
+                // ---- leave the part table for the pack kernel: {first byte, end} in the literal buffer and the address
+                // that byte 0 of the buffer would have in the part's scratch region
+                uint32_t const valid = j == 0 ? val0 : j == 1 ? val1 : j == 2 ? val2 : val3;
+                uint32_t const myHead = j == 0 ? hd0 : j == 1 ? hd1 : j == 2 ? hd2 : hd3;
+                uint32_t const dOff = j == 0 ? 0u : j == 1 ? val0 : j == 2 ? val0 + val1 : val0 + val1 + val2;
+                uint32_t const dStart = k * g.seg + dOff;
+                uintptr_t const delta = (uintptr_t)(tmpL + myHead) - dStart;
+                p.packTab[(size_t)job * kPackTabEntries + 4 * k + j] = make_uint4(dStart, dStart + valid, (uint32_t)delta, (uint32_t)((uint64_t)delta >> 32));
+            }
+#ifdef ZG_STAMPS
+            if (p.dbg && sl == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); uint64_t* const q = p.dbg + 16 * (size_t)p.nBlocks + 16 * (size_t)b; q[5] = z2 - z1; q[6] = __builtin_readcyclecounter() - z2; }
+#endif
+        }
+    }
+    uint32_t const maxCntSerial = specDone ? 0u : maxCnt;
+
+    // Input windows: per stream 24 aligned 16-byte units ending just above its unread bits.  A round consumes at most
+    // 1536 bits (usually far less); the windows are loaded again only when some stream's window could not feed
+    // another round.
+    uintptr_t wb[4] = {0, 0, 0, 0};
+    for (uint32_t r0 = 0; r0 < maxCntSerial; r0 += kHufRound) {
+#ifdef ZG_STAMPS
+        uint64_t const ya = __builtin_readcyclecounter();
+#endif
+        // 1. windows: does any stream of this block need a new one?
+        uintptr_t const curWb = sl == 0 ? wb[0] : sl == 1 ? wb[1] : sl == 2 ? wb[2] : wb[3];
+        bool const low = sl < nStreams && !bad && done < myCnt &&
+                         (int)(8 * (int64_t)((uintptr_t)myStart - curWb)) + bitsLeft < (int)(12 * kHufRound + 96);
+        bool const stage = r0 == 0 || ((__ballot(low) >> lead) & 0xFFFFu) != 0;
         uint4 v[6];
+        if (stage) {
 #pragma unroll
-        for (int j = 0; j < 6; j++) {
-            uint32_t const u = sl + 16 * j, k = (u * 43u) >> 10, iu = u - 24 * k;    // u / 24 for u < 96
-            uintptr_t const base = k == 0 ? wb[0] : k == 1 ? wb[1] : k == 2 ? wb[2] : wb[3];
-            v[j] = ld_unit(base + 16 * iu, floorAddr);
+            for (int k = 0; k < 4; k++) {
+                int const bl = __shfl(bitsLeft, lead + k);
+                uintptr_t const top = (uintptr_t)(cs + g.sOff(k)) + (uintptr_t)((bl > 0 ? bl + 7 : 0) >> 3);
+                wb[k] = ((top + 15) & ~(uintptr_t)15) - 4 * kHufInDw;
+            }
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+                uint32_t const u = sl + 16 * j, k = (u * 43u) >> 10, iu = u - 24 * k;    // u / 24 for u < 96
+                uintptr_t const base = k == 0 ? wb[0] : k == 1 ? wb[1] : k == 2 ? wb[2] : wb[3];
+                v[j] = ld_unit(base + 16 * iu, floorAddr);
+            }
         }
+#ifdef ZG_STAMPS
+        uint64_t const yb = __builtin_readcyclecounter();
+#endif
         // 2. flush the previous round's bytes (stores younger than the loads above: not waited for in this round)
         if (r0 > 0) huf_flush(out, outStage, g, r0 - kHufRound, nStreams, sl);
         lds_sync();     // the flush has read the stages
+#ifdef ZG_STAMPS
+        uint64_t const yc = __builtin_readcyclecounter();
+#endif
+        if (stage) {
 #pragma unroll
-        for (int j = 0; j < 6; j++) *(uint4*)(inWin + 4 * (sl + 16 * j)) = v[j];
+            for (int j = 0; j < 6; j++) *(uint4*)(inWin + 4 * (sl + 16 * j)) = v[j];
+        }
         lds_sync();
+#ifdef ZG_STAMPS
+        uint64_t const yd = __builtin_readcyclecounter();
+#endif
         // 3. decode up to 128 symbols of my stream, LDS only (HUF_decodeStreamX1, huf_decompress.pas:301-349)
         if (sl < nStreams && !bad && done < myCnt) {
             uint32_t const n = myCnt - done < kHufRound ? myCnt - done : kHufRound;
@@ -527,48 +765,6 @@ __global__ __launch_bounds__(64) void k_literals(BatchParams p)
             const uint32_t* const win = inWin + sl * kHufInDw;
             uint32_t* const so = (uint32_t*)(outStage + sl * kHufRound);
             uint32_t i = 0;
-            if (dbl) {
-                // double-symbol cells: 4 lookups (<= 44 bits, 4..8 symbols) per 64-bit peek.  A lookup writes two bytes;
-                // the second is overwritten by the next lookup when the cell held one symbol.
-                const uint32_t* const x2 = (const uint32_t*)tab;
-                uint8_t* const sb = (uint8_t*)so;
-                uint32_t const o0 = 32 - kHufDblLog;
-                for (; i + 8 <= n;) {
-                    uint32_t tHi, tLo;
-                    peek64(win, Q, tHi, tLo);
-                    uint32_t const c0 = x2[tHi >> o0];
-                    uint32_t o = o0 - __builtin_amdgcn_ubfe(c0, 20, 4);
-                    uint32_t const c1 = x2[__builtin_amdgcn_ubfe(tHi, o, kHufDblLog)];
-                    o -= __builtin_amdgcn_ubfe(c1, 20, 4);
-                    uint32_t const used2 = o0 - o;                       // <= 22
-                    uint32_t const t2 = shl_hi(tHi, tLo, used2);
-                    uint32_t const c2 = x2[t2 >> o0];
-                    uint32_t o2 = o0 - __builtin_amdgcn_ubfe(c2, 20, 4);
-                    uint32_t const c3 = x2[__builtin_amdgcn_ubfe(t2, o2, kHufDblLog)];
-                    o2 -= __builtin_amdgcn_ubfe(c3, 20, 4);
-                    uint16_t const w0 = (uint16_t)c0, w1 = (uint16_t)c1, w2 = (uint16_t)c2, w3 = (uint16_t)c3;
-                    __builtin_memcpy(sb + i, &w0, 2); i += 1 + (c0 >> 24);
-                    __builtin_memcpy(sb + i, &w1, 2); i += 1 + (c1 >> 24);
-                    __builtin_memcpy(sb + i, &w2, 2); i += 1 + (c2 >> 24);
-                    __builtin_memcpy(sb + i, &w3, 2); i += 1 + (c3 >> 24);
-                    Q -= used2 + (o0 - o2);
-                }
-                for (; i + 2 <= n;) {
-                    uint32_t tHi, tLo;
-                    peek64(win, Q, tHi, tLo);
-                    uint32_t const c0 = x2[tHi >> o0];
-                    uint16_t const w0 = (uint16_t)c0;
-                    __builtin_memcpy(sb + i, &w0, 2); i += 1 + (c0 >> 24);
-                    Q -= __builtin_amdgcn_ubfe(c0, 20, 4);
-                }
-                if (i < n) {      // one symbol left: the first of the cell
-                    uint32_t tHi, tLo;
-                    peek64(win, Q, tHi, tLo);
-                    uint32_t const c0 = x2[tHi >> o0];
-                    sb[i] = (uint8_t)c0; i++;
-                    Q -= __builtin_amdgcn_ubfe(c0, 16, 4);
-                }
-            }
             for (; i + 4 <= n; i += 4) {     // 4 symbols (<= 48 bits) per 64-bit peek
                 uint32_t tHi, tLo;
                 peek64(win, Q, tHi, tLo);
@@ -594,14 +790,87 @@ __global__ __launch_bounds__(64) void k_literals(BatchParams p)
             done += n;
         }
         lds_sync();
+#ifdef ZG_STAMPS
+        { uint64_t const ye = __builtin_readcyclecounter(); yA += yb - ya; yB += yc - yb; yC += yd - yc; yD += ye - yd; yN += 1; yS += stage ? 1 : 0; }
+#endif
     }
-    if (maxCnt > 0) huf_flush(out, outStage, g, ((maxCnt - 1) / kHufRound) * kHufRound, nStreams, sl);
+    if (maxCntSerial > 0) huf_flush(out, outStage, g, ((maxCntSerial - 1) / kHufRound) * kHufRound, nStreams, sl);
     // every stream must end exactly at its first bit (BIT_endOfDStream, huf_decompress.pas:553-555)
-    if (sl < nStreams && !bad && bitsLeft != 0) bad = true;
+    if (sl < nStreams && !bad && !specDone && bitsLeft != 0) bad = true;
     unsigned long long const anyBad = __ballot(bad);
     if (sl == 0) {
         uint32_t const mine = (uint32_t)((anyBad >> lead) & ((1u << kHufLanes) - 1));
         p.state[b].litErr = err ? err : (mine ? (uint32_t)E_corruption : 0u);
+        p.packTab[(size_t)job * kPackTabEntries + 16] = make_uint4(specDone ? 1u : 0u, 0, 0, 0);     // does the pack kernel have work for this block?
+#ifdef ZG_STAMPS
+        if (p.dbg) { uint64_t* const q = p.dbg + 16 * (size_t)p.nBlocks + 16 * (size_t)b; q[0] = y1 - y0; if (!specDone) { q[1] = yA; q[2] = yB; q[3] = yC; q[4] = yD; q[5] = yN; q[6] = yS; } q[7] = __builtin_readcyclecounter() - y0; q[8] = blk.litSize; q[9] = yp - y0; q[10] = yf - yp; q[11] = y1 - yf; }
+#endif
+    }
+}
+
+// Literals of a block that were decoded in 16 parts (split decode above): copy every part's valid bytes from its
+// scratch region to its place in the literal buffer.  One workgroup per block; the destination is dense, so the
+// workgroup walks it in 16-byte units (all loads of a thread first, then its stores); a unit that lies in one part is
+// one 16-byte copy, a unit that spans parts goes byte by byte.
+typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(1)));     // 16 bytes at any address
+constexpr int kPackThreads = 256;
+constexpr int kPackUnits = 12;      // units per thread and pass: 256 x 12 x 16 bytes = 48 KB, a whole block's literals in most cases
+__global__ __launch_bounds__(kPackThreads) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_pack_literals(BatchParams p)
+{
+    __shared__ uint4 parts[16];
+    uint32_t const job = blockIdx.x, tid = threadIdx.x;
+    const uint4* const tab = p.packTab + (size_t)job * kPackTabEntries;
+    if (tab[16].x == 0) return;
+    if (tid < 16) parts[tid] = tab[tid];
+    __syncthreads();
+    DevBlock const blk = p.blocks[p.litJobs[job]];
+    uint8_t* const out = p.litBuf + blk.litBufOff;
+    uint32_t const litSize = blk.litSize, nUnits = (litSize + 15) >> 4;
+    // part of buffer byte d: the first one that ends after d
+    auto part_of = [&](uint32_t d) -> uint32_t {
+        uint32_t q = 0;
+#pragma unroll
+        for (int stepq = 8; stepq >= 1; stepq >>= 1) q += parts[q + stepq - 1].y <= d ? (uint32_t)stepq : 0u;
+        return q < 15 ? q : 15u;
+    };
+    for (uint32_t first = 0; first < nUnits; first += kPackThreads * kPackUnits) {
+        uint4 x[kPackUnits];
+        bool whole[kPackUnits];
+#pragma unroll
+        for (int e = 0; e < kPackUnits; e++) {
+            uint32_t const u = first + (uint32_t)e * kPackThreads + tid, d = 16 * u;
+            whole[e] = false;
+            if (u < nUnits) {
+                uint4 const pt = parts[part_of(d)];
+                whole[e] = d >= pt.x && d + 16 <= pt.y;
+                // (a unit that is not copied whole reads the start of the scratch buffer instead: the loads stay unconditional)
+                const uint8_t* const from = whole[e] ? (const uint8_t*)((((uintptr_t)pt.w) << 32 | pt.z) + d) : p.litTmp;
+                u32x4u const val = *(const u32x4u*)from;
+                x[e] = make_uint4(val.x, val.y, val.z, val.w);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < kPackUnits; e++) {
+            uint32_t const u = first + (uint32_t)e * kPackThreads + tid;
+            if (whole[e]) *(uint4*)(out + 16 * (size_t)u) = x[e];
+        }
+    }
+    // units that span parts (or the end of the buffer) each hold the end of some part: one thread per part gathers
+    // the bytes of that unit, all loads in flight together
+    if (tid < 16) {
+        uint32_t const e = parts[tid].y;
+        if (e & 15u) {
+            uint32_t const d = e & ~15u;
+            uint8_t by[16];
+#pragma unroll
+            for (int c = 0; c < 16; c++) {
+                uint32_t const bq = d + (uint32_t)c < litSize ? d + (uint32_t)c : litSize - 1;
+                uint4 const pc = parts[part_of(bq)];
+                by[c] = *(const uint8_t*)((((uintptr_t)pc.w) << 32 | pc.z) + bq);
+            }
+#pragma unroll
+            for (int c = 0; c < 16; c++) if (d + (uint32_t)c < litSize) out[d + c] = by[c];
+        }
     }
 }
 
@@ -1910,6 +2179,7 @@ void launch_literals(const BatchParams& p, void* stream)
 {
     if (!p.nLitJobs) return;
     hipLaunchKernelGGL(k_literals, dim3((p.nLitJobs + kHufJobs - 1) / kHufJobs), dim3(64), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(k_pack_literals, dim3(p.nLitJobs), dim3(kPackThreads), 0, (hipStream_t)stream, p);
 }
 void launch_sequences(const BatchParams& p, void* stream)
 {

@@ -175,8 +175,8 @@ struct zstdgpu_batch {
     std::vector<DevFrame> hFrames;
     std::vector<uint32_t> hLitJobs, hSeqJobs;
     DevBlock* dBlocks = nullptr; DevBlockState* dState = nullptr; DevFrame* dFrames = nullptr; DevFrameStatus* dStatus = nullptr;
-    uint8_t* dLitBuf = nullptr; uint32_t* dSeqBuf = nullptr; uint32_t *dLitJobs = nullptr, *dSeqJobs = nullptr;
-    size_t litBufBytes = 0, seqBufBytes = 0;      // real sizes of the two big buffers (they return to the context's spare list)
+    uint8_t* dLitBuf = nullptr; uint8_t* dLitTmp = nullptr; uint4* dPackTab = nullptr; uint32_t* dSeqBuf = nullptr; uint32_t *dLitJobs = nullptr, *dSeqJobs = nullptr;
+    size_t litBufBytes = 0, litTmpBytes = 0, seqBufBytes = 0;      // real sizes of the two big buffers (they return to the context's spare list)
     uint64_t litBytes = 0, nSeqTotal = 0, srcBytes = 0, scratchBytes = 0;
     bool profiling = false;
     hipEvent_t ev[ZSTDGPU_NUM_STAGES + 1] = {};
@@ -286,8 +286,8 @@ void parse_sections(const uint8_t* payload, DevBlock& d)
 void free_batch_device(zstdgpu_batch* b)
 {
     hipFree(b->dBlocks); hipFree(b->dState); hipFree(b->dFrames); hipFree(b->dStatus);
-    bfree(b->ctx, b->dLitBuf, b->litBufBytes); bfree(b->ctx, b->dSeqBuf, b->seqBufBytes);
-    hipFree(b->dLitJobs); hipFree(b->dSeqJobs);
+    bfree(b->ctx, b->dLitBuf, b->litBufBytes); bfree(b->ctx, b->dLitTmp, b->litTmpBytes); bfree(b->ctx, b->dSeqBuf, b->seqBufBytes);
+    hipFree(b->dLitJobs); hipFree(b->dSeqJobs); hipFree(b->dPackTab);
     if (b->evReady) for (auto& e : b->ev) hipEventDestroy(e);
 }
 
@@ -459,7 +459,7 @@ extern "C" zstdgpu_batch* zstdgpu_batch_create(zstdgpu_ctx* ctx, const void* hos
     uint32_t const batchDictID = ddict ? ddict->dictID : 0;
     B->hBlocks.resize(nBlocks);
     B->hFrames.resize(nFrames);
-    uint64_t litOff = 0, seqOff = 0;
+    uint64_t litOff = 0, seqOff = 0, tmpOff = 0;
     for (uint32_t fi = 0; fi < nFrames; fi++) {
         const zstdgpu_frame_desc& fd = frames[fi];
         DevFrame& f = B->hFrames[fi];
@@ -495,6 +495,7 @@ extern "C" zstdgpu_batch* zstdgpu_batch_create(zstdgpu_ctx* ctx, const void* hos
             if (d.litType >= SET_COMPRESSED) {
                 d.litBufOff = litOff;
                 litOff += (d.litSize + 15) & ~15ull;
+                if (!d.singleStream) { d.litTmpOff = tmpOff; tmpOff += 16ull * litTmpLane(d.litSize); }
                 B->hLitJobs.push_back(b);
             }
             if (d.hostSeqErr) { dead = true; continue; }
@@ -512,8 +513,8 @@ extern "C" zstdgpu_batch* zstdgpu_batch_create(zstdgpu_ctx* ctx, const void* hos
     B->litBytes = litOff + 64; B->nSeqTotal = seqOff;
     bool ok = dalloc(B->dBlocks, nBlocks, B->scratchBytes) && dalloc(B->dState, nBlocks, B->scratchBytes) &&
               dalloc(B->dFrames, nFrames, B->scratchBytes) && dalloc(B->dStatus, nFrames, B->scratchBytes) &&
-              balloc(ctx, B->dLitBuf, B->litBytes, B->litBufBytes, B->scratchBytes) && balloc(ctx, B->dSeqBuf, seqOff * 4 + 4, B->seqBufBytes, B->scratchBytes) &&
-              dalloc(B->dLitJobs, B->hLitJobs.size(), B->scratchBytes) && dalloc(B->dSeqJobs, B->hSeqJobs.size(), B->scratchBytes);
+              balloc(ctx, B->dLitBuf, B->litBytes, B->litBufBytes, B->scratchBytes) && balloc(ctx, B->dLitTmp, tmpOff + 64, B->litTmpBytes, B->scratchBytes) && balloc(ctx, B->dSeqBuf, seqOff * 4 + 4, B->seqBufBytes, B->scratchBytes) &&
+              dalloc(B->dLitJobs, B->hLitJobs.size(), B->scratchBytes) && dalloc(B->dPackTab, B->hLitJobs.size() * 17 + 1, B->scratchBytes) && dalloc(B->dSeqJobs, B->hSeqJobs.size(), B->scratchBytes);
     auto up = [&](void* d, const void* h, size_t n) { return n == 0 || hipMemcpy(d, h, n, hipMemcpyHostToDevice) == hipSuccess; };
     ok = ok && up(B->dBlocks, B->hBlocks.data(), nBlocks * sizeof(DevBlock)) && up(B->dFrames, B->hFrames.data(), nFrames * sizeof(DevFrame)) &&
          up(B->dLitJobs, B->hLitJobs.data(), B->hLitJobs.size() * 4) && up(B->dSeqJobs, B->hSeqJobs.data(), B->hSeqJobs.size() * 4);
@@ -548,7 +549,7 @@ extern "C" size_t zstdgpu_batch_decode(zstdgpu_batch* B, const void* devSrc, voi
     BatchParams p{};
     p.src = (const uint8_t*)devSrc; p.dst = (uint8_t*)devDst;
     p.blocks = B->dBlocks; p.state = B->dState; p.frames = B->dFrames; p.status = B->dStatus;
-    p.litBuf = B->dLitBuf; p.seqBuf = B->dSeqBuf; p.litJobs = B->dLitJobs; p.seqJobs = B->dSeqJobs;
+    p.litBuf = B->dLitBuf; p.litTmp = B->dLitTmp; p.packTab = B->dPackTab; p.seqBuf = B->dSeqBuf; p.litJobs = B->dLitJobs; p.seqJobs = B->dSeqJobs;
     p.nLitJobs = (uint32_t)B->hLitJobs.size(); p.nSeqJobs = (uint32_t)B->hSeqJobs.size();
     p.nFrames = (uint32_t)B->hFrames.size(); p.nBlocks = (uint32_t)B->hBlocks.size();
     if (B->ddict) {
@@ -558,8 +559,8 @@ extern "C" size_t zstdgpu_batch_decode(zstdgpu_batch* B, const void* devSrc, voi
     }
 #ifdef ZG_STAMPS
     static uint64_t* dbgBuf = nullptr; static size_t dbgCap = 0;
-    if (dbgCap < p.nBlocks) { hipFree(dbgBuf); hipMalloc((void**)&dbgBuf, (size_t)p.nBlocks * 64); dbgCap = p.nBlocks; }
-    hipMemsetAsync(dbgBuf, 0, (size_t)p.nBlocks * 64, s);
+    if (dbgCap < p.nBlocks) { hipFree(dbgBuf); hipMalloc((void**)&dbgBuf, (size_t)p.nBlocks * 256); dbgCap = p.nBlocks; }
+    hipMemsetAsync(dbgBuf, 0, (size_t)p.nBlocks * 256, s);
     p.dbg = dbgBuf;
 #endif
     bool const prof = B->profiling && B->evReady;
@@ -579,8 +580,21 @@ extern "C" size_t zstdgpu_batch_decode(zstdgpu_batch* B, const void* devSrc, voi
 #ifdef ZG_STAMPS
     {   // diagnostic build: print where the sequence stage spends its cycles
         hipStreamSynchronize(s);
-        std::vector<uint64_t> h((size_t)p.nBlocks * 8);
+        std::vector<uint64_t> h((size_t)p.nBlocks * 32);
         hipMemcpy(h.data(), dbgBuf, h.size() * 8, hipMemcpyDeviceToHost);
+        {   // literal stage, the blocks with the most literals (they set the kernel's duration)
+            double u[12] = {0}; size_t m = 0; uint64_t big = 0;
+            for (size_t i = 0; i < p.nBlocks; i++) { const uint64_t* q = h.data() + 16 * p.nBlocks + 16 * i; if (q[8] > big) big = q[8]; }
+            for (size_t i = 0; i < p.nBlocks; i++) { const uint64_t* q = h.data() + 16 * p.nBlocks + 16 * i; if (q[7] && q[8] * 10 >= big * 9) { for (int j = 0; j < 12; j++) u[j] += q[j]; m++; } }
+            if (m) fprintf(stderr, "[stamps] k_literals, %zu largest blocks (%.0f literal bytes): table %.0f  loads+flush %.0f  sync+window-write %.0f  decode %.0f  loop %.0f  total %.0f ticks; %.0f rounds, %.0f restaged; table = parse %.0f + fill %.0f + %.0f\n",
+                           m, u[8] / m, u[0] / m, u[1] / m, u[2] / m, u[3] / m, u[4] / m, u[7] / m, u[5] / m, u[6] / m, u[9] / m, u[10] / m, u[11] / m);
+        }
+        {
+            size_t hist[128] = {0}; size_t shown = 0;
+            for (size_t i = 0; i < p.nBlocks; i++) { const uint64_t* q = h.data() + 16 * p.nBlocks + 16 * i; hist[q[12] & 127]++;
+                if ((q[12] & 7) && shown < 6) { fprintf(stderr, "[stamps] split decode block %zu: why 0x%llx sum %llu want %llu idx/valid %llx\n", i, (unsigned long long)q[12], (unsigned long long)q[13], (unsigned long long)q[14], (unsigned long long)q[15]); shown++; } }
+            for (int w = 0; w < 128; w++) if (hist[w]) fprintf(stderr, "[stamps] split decode why 0x%x: %zu blocks\n", w, hist[w]);
+        }
         double t[8] = {0}; size_t n = 0;
         for (size_t i = 0; i < p.nFrames; i++) if (h[8 * i + 5]) { for (int j = 0; j < 8; j++) t[j] += h[8 * i + j]; n++; }
         if (n) fprintf(stderr, "[stamps] k_execute per frame: setup %.0f  load-issue %.0f  load-wait %.0f  assemble+store %.0f  rest %.0f ticks; %.0f batches, %.0f extra passes, %.0f staged\n",

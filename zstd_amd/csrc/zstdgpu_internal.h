@@ -17,6 +17,9 @@ enum : uint8_t { BT_RAW = 0, BT_RLE = 1, BT_COMPRESSED = 2, BT_STOP = 3 };   // 
 enum : uint8_t { SET_BASIC = 0, SET_RLE = 1, SET_COMPRESSED = 2, SET_REPEAT = 3 };  // symbolEncodingType_e (zstd_internal.pas:112-118)
 
 constexpr uint32_t kBlockSizeMax = 1u << 17;
+// bytes per lane region of the split literal decode: a quarter stream regenerates about litSize/16 bytes; twice that
+// plus slack is allowed before the block falls back to whole-stream decoding
+constexpr uint32_t litTmpLane(uint32_t litSize) { return ((litSize + 3) / 4 / 2 + 256 + 31) & ~31u; }
 constexpr uint32_t kSymbolicRep = 0x80000000u;   // sequence offset / rep value that refers to the block's incoming rep stack
 
 // Per-block descriptor consumed by the kernels (built on the host).
@@ -24,6 +27,7 @@ struct DevBlock {
     uint64_t srcOff;       // block payload in the source buffer
     uint64_t litBufOff;    // decoded literals go here (litType compressed/repeat)
     uint64_t seqBufOff;    // first sequence slot of this block
+    uint64_t litTmpOff;    // 4-stream Huffman literals: 16 regions of litTmpLane(litSize) bytes for the split decode
     uint32_t cSize;
     uint32_t origSize;     // raw/RLE regenerated size
     uint32_t frameIdx;
@@ -92,6 +96,8 @@ struct BatchParams {
     const DevFrame* frames;
     DevFrameStatus* status;
     uint8_t* litBuf;
+    uint4* packTab;              // split literal decode: per literal job 16 parts {start, end, source address} + a flag
+    uint8_t* litTmp;             // scratch of the split literal decode (may be null: streams are then decoded whole)
     uint32_t* seqBuf;            // triples (litLength, matchLength, offset)
     const uint32_t* litJobs;     // block indices with Huffman-coded literals
     const uint32_t* seqJobs;     // block indices with nbSeq > 0
