@@ -35,6 +35,13 @@ def small_alphabet(seed: int, n: int, k: int) -> bytes:
     return bytes(rnd.choice(b"ACGTNXYZ01234567"[:k]) for _ in range(n))
 
 
+def slow_sync(seed: int, n: int, eps: float) -> bytes:
+    """15 equiprobable symbols and two rare ones: nearly every Huffman code has the same length, so a decoder that
+    starts off a code boundary stays off it until a rare symbol comes by (every 1/eps symbols)."""
+    rnd = random.Random(seed)
+    return bytes(rnd.choices(range(17), weights=[(1 - eps) / 15] * 15 + [eps / 2] * 2, k=n))
+
+
 def many_sequences(seed: int, n: int, n_words: int = 48, lens=(3, 4)) -> bytes:
     """3-4 byte words from a small set, each followed by one random byte: one sequence per ~4.5 bytes."""
     rnd = random.Random(seed)
@@ -63,12 +70,11 @@ def records(seed: int, n_records: int, size: int = 4096):
     return out
 
 
-def huf12_frame(seed: int, n: int, single_stream: bool) -> bytes:
-    """A hand-made frame libzstd never produces: one compressed block, literals only (no sequences), Huffman
-    table of the maximum depth the format allows (code lengths 1..12, tableLog 12), direct 4-bit weights."""
-    lens = [2, 2, 2] + list(range(3, 13)) + [12]            # symbol s has a code of lens[s] bits; Kraft sum = 1
-    nsym = len(lens)                                       # (a weight must stay below 12, so no code is shorter than 2 bits)
-    weights = [13 - l for l in lens]                       # weight = tableLog + 1 - nbBits
+def handmade_huf_frame(lens, probs, seed: int, n: int, single_stream: bool):
+    """A hand-made frame: one compressed block, literals only (no sequences), Huffman table with the given code
+    lengths (Kraft sum 1) written as direct 4-bit weights, symbols drawn with the given probabilities."""
+    nsym, log = len(lens), max(lens)
+    weights = [log + 1 - l for l in lens]                  # weight = tableLog + 1 - nbBits
     # canonical codes as the decoder's table lays them out: weights ascending, symbols ascending inside a weight
     order = sorted(range(nsym), key=lambda sym: (weights[sym], sym))
     code, start = {}, 0
@@ -76,9 +82,9 @@ def huf12_frame(seed: int, n: int, single_stream: bool) -> bytes:
         w = weights[sym]
         code[sym] = start >> (w - 1)
         start += 1 << (w - 1)
-    assert start == 4096
+    assert start == 1 << log
     rnd = random.Random(seed)
-    data = bytes(rnd.choices(range(nsym), weights=[2.0 ** -l for l in lens], k=n))
+    data = bytes(rnd.choices(range(nsym), weights=probs, k=n))
 
     def stream(seg: bytes) -> bytes:
         acc, nbits = 0, 0
@@ -97,11 +103,23 @@ def huf12_frame(seed: int, n: int, single_stream: bool) -> bytes:
     else:
         seg = (n + 3) // 4
         parts = [stream(data[i * seg:(i + 1) * seg]) for i in range(4)]
+        assert all(len(x) < 65536 for x in parts[:3])
         body = desc + b"".join(struct.pack("<H", len(x)) for x in parts[:3]) + b"".join(parts)
         lit = (2 | (3 << 2) | (n << 4) | (len(body) << 22)).to_bytes(5, "little")
     block = lit + body + b"\x00"                           # no sequences
-    hdr = struct.pack("<I", 0xFD2FB528) + bytes([0x60]) + struct.pack("<H", n - 256)    # single segment, 2-byte content size
+    assert len(block) < 128 * KB
+    if n < 65536 + 256:
+        hdr = struct.pack("<I", 0xFD2FB528) + bytes([0x60]) + struct.pack("<H", n - 256)    # single segment, 2-byte content size
+    else:
+        hdr = struct.pack("<I", 0xFD2FB528) + bytes([0xA0]) + struct.pack("<I", n)          # single segment, 4-byte content size
     return hdr + (1 | (2 << 1) | (len(block) << 3)).to_bytes(3, "little") + block, data
+
+
+def huf12_frame(seed: int, n: int, single_stream: bool):
+    """Huffman table of the maximum depth the format allows (code lengths 2..12, tableLog 12): libzstd never
+    produces one (a weight must stay below 12, so no code is shorter than 2 bits)."""
+    lens = [2, 2, 2] + list(range(3, 13)) + [12]
+    return handmade_huf_frame(lens, [2.0 ** -l for l in lens], seed, n, single_stream)
 
 
 def main():
@@ -173,6 +191,10 @@ def main():
         add(f"alpha{k}_{n}", z.compress(small_alphabet(k * 1000 + n, n, k), 3), n, note="few/no sequences, Huffman literals")
     add("alpha16_l19", z.compress(small_alphabet(5, 128 * KB, 16), 19, True), 128 * KB, note="Huffman literals level 19")
 
+    # literals whose Huffman streams resynchronise slowly (the split literal decode has to carry on across parts, or give up)
+    for eps in (0.02, 0.004, 0.001):
+        add(f"slowsync_{eps}", z.compress(slow_sync(91, 128 * KB, eps), 3), 128 * KB, note="Huffman codes of nearly equal length")
+
     # Huffman table of 12 bits (the decoder's limit; encoders stop at 11): hand-made frames, 4 streams and 1 stream
     fr, plain = huf12_frame(81, 20000, False)
     out, err = add("huf12_4streams", fr, 20000, note="hand-made: tableLog 12 Huffman literals, 4 streams, no sequences")
@@ -180,6 +202,17 @@ def main():
     fr, plain = huf12_frame(82, 900, True)
     out, err = add("huf12_1stream", fr, 900, note="hand-made: tableLog 12 Huffman literals, single stream, no sequences")
     assert not err and out == plain, (err,)
+
+    # Huffman streams that resynchronise slowly: fifteen 4-bit codes and two 5-bit ones; the data uses three of the 4-bit
+    # symbols (codes with few 1 bits, so a decoder off the code boundaries never mistakes anything for a 5-bit code) and,
+    # rarely, the 5-bit symbols, which alone shift the boundaries.  The split literal decode has to carry on across
+    # quarter points (or, with no 5-bit symbols at all, give up and decode the streams whole).
+    for name, eps in (("rare", 1.0 / 800), ("never", 0.0)):
+        lens = [4] * 15 + [5, 5]
+        probs = [(1 - eps) / 3] * 3 + [1e-12] * 12 + [eps / 2 + 1e-12] * 2
+        fr, plain = handmade_huf_frame(lens, probs, 83, 120001, False)
+        out, err = add(f"hufsync_{name}", fr, 120001, note="hand-made: Huffman codes of (almost) one length, 4 streams, no sequences")
+        assert not err and out == plain, (err,)
 
     # ---- sequence-heavy blocks: nbSeq >= 0x7F00 needs the 3-byte count ---------------------------------
     data = many_sequences(21, 128 * KB)
