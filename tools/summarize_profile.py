@@ -15,7 +15,7 @@ import sys
 
 
 def per_kernel(path, pick):
-    rows = list(csv.DictReader(open(glob.glob(os.path.join(path, "*", "*_counter_collection.csv"))[0])))
+    rows = list(csv.DictReader(open(max(glob.glob(os.path.join(path, "*", "*_counter_collection.csv")), key=os.path.getmtime))))   # newest run
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in rows:
         if "zg::" in r["Kernel_Name"]:
@@ -28,7 +28,7 @@ def main():
     src, tag = sys.argv[1], sys.argv[2]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = {"tag": tag, "kernels": {}}
-    stats = list(csv.DictReader(open(glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))[0])))
+    stats = list(csv.DictReader(open(max(glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv")), key=os.path.getmtime))))
     for r in stats:
         if "zg::" in r["Name"]:
             name = re.search(r"(k_\w+)", r["Name"]).group(1)
