@@ -96,11 +96,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU decode path)"
+    # Rehearsal on a box with fewer GPUs than ranks: BENCH_REHEARSAL=1 puts every rank on GPU 0 and uses gloo for the
+    # two collectives (RCCL refuses two ranks on one device).  The driver's runs never set it.
+    rehearsal = os.environ.get("BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     n = args.frames
     from zstd_amd import sharding
@@ -137,7 +145,7 @@ def main():
         stage += np.array(batch.stage_ms())      # waits for this step's last event; steps are serial on one stream anyway
     barrier()
     elapsed = time.perf_counter() - t0
-    elapsed = sharding.max_over_ranks(dist, elapsed, device="cuda")
+    elapsed = sharding.max_over_ranks(dist, elapsed, device="cpu" if rehearsal else "cuda")
     stage /= args.steps
 
     # ---- verification, outside the timed region: verdicts, sizes, and every output byte via XXH64
