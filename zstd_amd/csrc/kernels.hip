@@ -2179,6 +2179,10 @@ void launch_literals(const BatchParams& p, void* stream)
 {
     if (!p.nLitJobs) return;
     hipLaunchKernelGGL(k_literals, dim3((p.nLitJobs + kHufJobs - 1) / kHufJobs), dim3(64), 0, (hipStream_t)stream, p);
+}
+void launch_pack_literals(const BatchParams& p, void* stream)
+{
+    if (!p.nLitJobs) return;
     hipLaunchKernelGGL(k_pack_literals, dim3(p.nLitJobs), dim3(kPackThreads), 0, (hipStream_t)stream, p);
 }
 void launch_sequences(const BatchParams& p, void* stream)

@@ -182,6 +182,9 @@ struct zstdgpu_batch {
     hipEvent_t ev[ZSTDGPU_NUM_STAGES + 1] = {};
     bool evReady = false, evRecorded = false;
     hipStream_t lastStream = nullptr;
+    // the literal pack kernel runs beside the sequence kernel on a stream of its own, forked and joined with events
+    hipStream_t side = nullptr;
+    hipEvent_t evFork = nullptr, evJoin = nullptr;
 };
 
 namespace {
@@ -289,6 +292,9 @@ void free_batch_device(zstdgpu_batch* b)
     bfree(b->ctx, b->dLitBuf, b->litBufBytes); bfree(b->ctx, b->dLitTmp, b->litTmpBytes); bfree(b->ctx, b->dSeqBuf, b->seqBufBytes);
     hipFree(b->dLitJobs); hipFree(b->dSeqJobs); hipFree(b->dPackTab);
     if (b->evReady) for (auto& e : b->ev) hipEventDestroy(e);
+    if (b->side) hipStreamDestroy(b->side);
+    if (b->evFork) hipEventDestroy(b->evFork);
+    if (b->evJoin) hipEventDestroy(b->evJoin);
 }
 
 }  // namespace
@@ -518,6 +524,8 @@ extern "C" zstdgpu_batch* zstdgpu_batch_create(zstdgpu_ctx* ctx, const void* hos
     auto up = [&](void* d, const void* h, size_t n) { return n == 0 || hipMemcpy(d, h, n, hipMemcpyHostToDevice) == hipSuccess; };
     ok = ok && up(B->dBlocks, B->hBlocks.data(), nBlocks * sizeof(DevBlock)) && up(B->dFrames, B->hFrames.data(), nFrames * sizeof(DevFrame)) &&
          up(B->dLitJobs, B->hLitJobs.data(), B->hLitJobs.size() * 4) && up(B->dSeqJobs, B->hSeqJobs.data(), B->hSeqJobs.size() * 4);
+    ok = ok && hipStreamCreateWithFlags(&B->side, hipStreamNonBlocking) == hipSuccess &&
+         hipEventCreateWithFlags(&B->evFork, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&B->evJoin, hipEventDisableTiming) == hipSuccess;
     if (!ok) { free_batch_device(B); delete B; return nullptr; }
     return B;
 }
@@ -568,10 +576,16 @@ extern "C" size_t zstdgpu_batch_decode(zstdgpu_batch* B, const void* devSrc, voi
     if (p.nBlocks) hipMemsetAsync(B->dState, 0, (size_t)p.nBlocks * sizeof(DevBlockState), s);
     launch_literals(p, s);
     if (prof) hipEventRecord(B->ev[1], s);
+    // the pack of split-decoded literals needs nothing from the sequence stage and leaves it most of the chip: side stream
+    hipEventRecord(B->evFork, s);
+    hipStreamWaitEvent(B->side, B->evFork, 0);
+    launch_pack_literals(p, B->side);
+    hipEventRecord(B->evJoin, B->side);
     launch_sequences(p, s);
     if (prof) hipEventRecord(B->ev[2], s);
     launch_layout(p, s);
     if (prof) hipEventRecord(B->ev[3], s);
+    hipStreamWaitEvent(s, B->evJoin, 0);
     launch_execute(p, s);
     if (prof) hipEventRecord(B->ev[4], s);
     launch_checksum(p, s);

@@ -112,6 +112,7 @@ struct BatchParams {
 
 // kernel launchers (kernels.hip)
 void launch_literals(const BatchParams& p, void* stream);
+void launch_pack_literals(const BatchParams& p, void* stream);
 void launch_sequences(const BatchParams& p, void* stream);
 void launch_layout(const BatchParams& p, void* stream);
 void launch_execute(const BatchParams& p, void* stream);
