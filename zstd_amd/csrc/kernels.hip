@@ -336,6 +336,104 @@ DEVI uint32_t dev_huf_read_table_desc(const uint8_t* src, uint32_t srcSize, Byte
     return iSize + 1;
 }
 
+// First half of HUF_readStats_body (entropy_common.pas:311-349): the weights as listed in the description, direct
+// or FSE-compressed.  One lane.  Returns the description's size in bytes or kFail; nListed = weights listed.
+template <typename BytePtr>
+DEVI uint32_t dev_huf_listed_weights(const uint8_t* src, uint32_t srcSize, BytePtr weights, uint8_t* scratch, uint32_t& nListed)
+{
+    if (srcSize == 0) return kFail;
+    uint32_t iSize = src[0];
+    if (iSize >= 128) {
+        nListed = iSize - 127;
+        iSize = (nListed + 1) / 2;
+        if (iSize + 1 > srcSize) return kFail;
+        for (uint32_t n = 0; n < nListed; n += 2) {
+            uint32_t const b = src[1 + n / 2];
+            weights[n] = (uint8_t)(b >> 4);
+            weights[n + 1] = (uint8_t)(b & 15);
+        }
+    } else {
+        if (iSize + 1 > srcSize) return kFail;
+        nListed = dev_fse_weights(weights, 255, src + 1, iSize, scratch);
+        if (nListed == kFail) return kFail;
+    }
+    return iSize + 1;
+}
+
+// Second half of HUF_readStats_body (:350-392) and the rank scan of HUF_readDTableX1_wksp (huf_decompress.pas:133-285)
+// by a group of 16 lanes (a DPP row): weight counts, the implied last weight, and pos[n] = first table cell of
+// symbol n (cells are laid out by weight, symbols in order inside a weight).  Lane l counts symbols 16 l .. 16 l + 15
+// in four words of three 10-bit counters (weights 0..11), a prefix sum over the lanes gives every lane the counts
+// before its symbols.  Returns false on an invalid description.  rank: 13 words of LDS.
+DEVI bool grp_huf_ranks(uint8_t* weights, uint16_t* pos, uint32_t* rank, uint32_t nListed, uint32_t gl, uint32_t lead, uint32_t& nbSymbols, uint32_t& tableLog)
+{
+    uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0, wsum = 0;
+    bool bad = false;
+    uint32_t myW[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+        uint32_t const n = 16 * gl + u;
+        uint32_t const w = n < nListed ? weights[n] : 0xFFu;
+        myW[u] = w;
+        if (n < nListed) {
+            if (w >= 12) bad = true;
+            uint32_t const inc = 1u << (10 * (w % 3));
+            uint32_t const word = w / 3;
+            c0 += word == 0 ? inc : 0u; c1 += word == 1 ? inc : 0u; c2 += word == 2 ? inc : 0u; c3 += word == 3 ? inc : 0u;
+            wsum += (1u << (w & 15)) >> 1;
+        }
+    }
+    if (((__ballot(bad) >> lead) & 0xFFFFu) != 0) return false;
+    // inclusive prefix over the row
+    uint32_t i0 = c0, i1 = c1, i2 = c2, i3 = c3, is = wsum;
+#define ZG_ROW_STEP(CTRL) i0 += dpp_or0<CTRL, 0xF>(i0); i1 += dpp_or0<CTRL, 0xF>(i1); i2 += dpp_or0<CTRL, 0xF>(i2); i3 += dpp_or0<CTRL, 0xF>(i3); is += dpp_or0<CTRL, 0xF>(is);
+    ZG_ROW_STEP(0x111) ZG_ROW_STEP(0x112) ZG_ROW_STEP(0x114) ZG_ROW_STEP(0x118)
+#undef ZG_ROW_STEP
+    uint32_t t0 = (uint32_t)__shfl((int)i0, (int)(lead + 15)), t1 = (uint32_t)__shfl((int)i1, (int)(lead + 15)),
+             t2 = (uint32_t)__shfl((int)i2, (int)(lead + 15)), t3 = (uint32_t)__shfl((int)i3, (int)(lead + 15));
+    uint32_t const weightTotal = (uint32_t)__shfl((int)is, (int)(lead + 15));
+    if (weightTotal == 0) return false;
+    tableLog = hb32(weightTotal) + 1;
+    if (tableLog > 12) return false;
+    uint32_t const rest = (1u << tableLog) - weightTotal;
+    if ((1u << hb32(rest)) != rest) return false;
+    uint32_t const lastWeight = hb32(rest) + 1;
+    auto total_of = [&](uint32_t w) -> uint32_t { uint32_t const word = w / 3 == 0 ? t0 : w / 3 == 1 ? t1 : w / 3 == 2 ? t2 : t3; return (word >> (10 * (w % 3))) & 1023u; };
+    uint32_t const lastBefore = total_of(lastWeight);          // symbols of that weight before the implied one
+    {   // the implied symbol joins its class
+        uint32_t const inc = 1u << (10 * (lastWeight % 3));
+        uint32_t const word = lastWeight / 3;
+        t0 += word == 0 ? inc : 0u; t1 += word == 1 ? inc : 0u; t2 += word == 2 ? inc : 0u; t3 += word == 3 ? inc : 0u;
+    }
+    uint32_t const n1 = total_of(1);
+    if (n1 < 2 || (n1 & 1)) return false;
+    nbSymbols = nListed + 1;
+    // rank[w] := first cell of weight class w
+    if (gl == 0) {
+        uint32_t next = 0;
+        rank[0] = 0;
+        for (uint32_t w = 1; w <= 12; w++) { rank[w] = next; next += total_of(w) << (w - 1); }
+        weights[nListed] = (uint8_t)lastWeight;
+        pos[nListed] = (uint16_t)(rank[lastWeight] + (lastBefore << (lastWeight - 1)));
+    }
+    lds_sync();
+    // this lane's symbols, on top of the counts of the lanes before it
+    uint32_t r0 = i0 - c0, r1 = i1 - c1, r2 = i2 - c2, r3 = i3 - c3;
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+        uint32_t const n = 16 * gl + u, w = myW[u];
+        if (n < nListed) {
+            uint32_t const word = w / 3 == 0 ? r0 : w / 3 == 1 ? r1 : w / 3 == 2 ? r2 : r3;
+            uint32_t const before = (word >> (10 * (w % 3))) & 1023u;
+            pos[n] = (uint16_t)(w ? rank[w] + (before << (w - 1)) : 0u);
+            uint32_t const inc = 1u << (10 * (w % 3));
+            r0 += w / 3 == 0 ? inc : 0u; r1 += w / 3 == 1 ? inc : 0u; r2 += w / 3 == 2 ? inc : 0u; r3 += w / 3 == 3 ? inc : 0u;
+        }
+    }
+    lds_sync();
+    return true;
+}
+
 // ---------------------------------------------------------------- stage 0: literals
 
 constexpr int kHufLanes = 16;                // lanes per literal job: 4 decode one stream each, all 16 move data
@@ -412,16 +510,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
         for (uint32_t i = sl; i < descAvail + 8; i += kHufLanes) hdrStage[i] = dp[(int)i - 8];
     }
     lds_sync();
+    uint32_t nListed = 0;
+    bool parse = false;         // a table description to digest (the group's first lane lists the weights, all 16 lanes rank them)
     if (sl == 0) {
         if (blk.litType == SET_COMPRESSED && !blk.singleStream && (blk.litSize == 0 || blk.litCSize == 0)) err = E_corruption;   // huf_decompress.pas:1421-1424
         else if (blk.hufSrc == SRC_NONE) err = E_corruption;
         else if (fromDict) tableLog = p.dict->hufLog;
         else {
             DevBlock const sb = (blk.hufSrc == (int32_t)b) ? blk : p.blocks[blk.hufSrc];
-            uint32_t const r = dev_huf_read_table_desc(hdrStage + 8, sb.litCSize, weights, pos, rank, tab, nbSymbols, tableLog);
+            uint32_t const r = dev_huf_listed_weights(hdrStage + 8, sb.litCSize, weights, tab, nListed);
             if (r == kFail) err = E_corruption;
             else {
                 hSize = r;
+                parse = true;
                 if (blk.litType == SET_COMPRESSED && hSize >= blk.litCSize) err = E_corruption;   // huf_decompress.pas:1394, :1349
             }
         }
@@ -431,7 +532,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
     uint64_t const yp = __builtin_readcyclecounter();
 #endif
     uint32_t const lead = sub * kHufLanes;
-    err = __shfl(err, lead); tableLog = __shfl(tableLog, lead); nbSymbols = __shfl(nbSymbols, lead); hSize = __shfl(hSize, lead);
+    err = __shfl(err, lead); tableLog = __shfl(tableLog, lead); hSize = __shfl(hSize, lead); nListed = __shfl(nListed, lead);
+    parse = __shfl((int)parse, lead) != 0;
+    if (parse && !err) {
+        if (!grp_huf_ranks(weights, pos, rank, nListed, sl, lead, nbSymbols, tableLog)) err = E_corruption;
+    }
 
     bool ok = (err == 0);
     uint16_t* const x1 = cells;
@@ -803,7 +908,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
         p.state[b].litErr = err ? err : (mine ? (uint32_t)E_corruption : 0u);
         p.packTab[(size_t)job * kPackTabEntries + 16] = make_uint4(specDone ? 1u : 0u, 0, 0, 0);     // does the pack kernel have work for this block?
 #ifdef ZG_STAMPS
-        if (p.dbg) { uint64_t* const q = p.dbg + 16 * (size_t)p.nBlocks + 16 * (size_t)b; q[0] = y1 - y0; if (!specDone) { q[1] = yA; q[2] = yB; q[3] = yC; q[4] = yD; q[5] = yN; q[6] = yS; } q[7] = __builtin_readcyclecounter() - y0; q[8] = blk.litSize; q[9] = yp - y0; q[10] = yf - yp; q[11] = y1 - yf; }
+        if (p.dbg) { uint64_t* const q = p.dbg + 16 * (size_t)p.nBlocks + 16 * (size_t)b; q[0] = y1 - y0; if (!specDone) { q[1] = yA; q[2] = yB; q[3] = yC; q[4] = yD; q[5] = yN; q[6] = yS; } q[7] = __builtin_readcyclecounter() - y0; q[8] = blk.litSize; q[9] = yp - y0; q[10] = yf - yp; q[11] = 0; }
 #endif
     }
 }

@@ -600,8 +600,8 @@ extern "C" size_t zstdgpu_batch_decode(zstdgpu_batch* B, const void* devSrc, voi
             double u[12] = {0}; size_t m = 0; uint64_t big = 0;
             for (size_t i = 0; i < p.nBlocks; i++) { const uint64_t* q = h.data() + 16 * p.nBlocks + 16 * i; if (q[8] > big) big = q[8]; }
             for (size_t i = 0; i < p.nBlocks; i++) { const uint64_t* q = h.data() + 16 * p.nBlocks + 16 * i; if (q[7] && q[8] * 10 >= big * 9) { for (int j = 0; j < 12; j++) u[j] += q[j]; m++; } }
-            if (m) fprintf(stderr, "[stamps] k_literals, %zu largest blocks (%.0f literal bytes): table %.0f  loads+flush %.0f  sync+window-write %.0f  decode %.0f  loop %.0f  total %.0f ticks; %.0f rounds, %.0f restaged; table = parse %.0f + fill %.0f + %.0f\n",
-                           m, u[8] / m, u[0] / m, u[1] / m, u[2] / m, u[3] / m, u[4] / m, u[7] / m, u[5] / m, u[6] / m, u[9] / m, u[10] / m, u[11] / m);
+            if (m) fprintf(stderr, "[stamps] k_literals, %zu largest blocks (%.0f literal bytes): table %.0f  loads+flush %.0f  sync+window-write %.0f  decode %.0f  loop %.0f  total %.0f ticks; %.0f rounds, %.0f restaged; table = parse %.0f (weights %.0f) + fill %.0f\n",
+                           m, u[8] / m, u[0] / m, u[1] / m, u[2] / m, u[3] / m, u[4] / m, u[7] / m, u[5] / m, u[6] / m, u[9] / m, u[11] / m, u[10] / m);
         }
         {
             size_t hist[128] = {0}; size_t shown = 0;
