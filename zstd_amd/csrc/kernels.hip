@@ -260,21 +260,31 @@ DEVI uint32_t dev_fse_weights(BytePtr weights, uint32_t maxOut, const uint8_t* s
         uint32_t const nb = tableLog - hb32(ns);
         dt[u] = (((ns << nb) - tableSize) << 16) | (nb << 8) | sym;
     }
-    BitR br;
-    if (!br.init(src + hSize, srcSize - hSize)) return kFail;
-    uint32_t s1 = br.read(tableLog); br.refill();
-    uint32_t s2 = br.read(tableLog); br.refill();
-    if (br.left() < 0) return kFail;   // states alone overran the stream: upstream decodes garbage here, never a valid header
+    // two-state decode.  `cur` = bits of the stream not yet read; every read looks at the 32 bits below the cursor
+    // (an 8-byte unaligned load that may start up to 4 bytes before the stream: other header bytes always precede it).
+    const uint8_t* const st = src + hSize;
+    uint32_t const stSize = srcSize - hSize;
+    if (stSize == 0) return kFail;                      // BIT_initDStream: empty stream
+    uint32_t const lastByte = st[stSize - 1];
+    if (lastByte == 0) return kFail;                    // no end mark
+    int cur = (int)(stSize * 8) - (int)(8 - hb32(lastByte));
+    auto read = [&](uint32_t nb) -> uint32_t {
+        int const bo = cur - 32;
+        uint32_t const t = (uint32_t)(ld_u64(st + (bo >> 3)) >> (bo & 7));
+        cur -= (int)nb;
+        return __builtin_amdgcn_ubfe(t, 32 - nb, nb);   // garbage once the cursor is below zero; callers stop there
+    };
+    uint32_t s1 = read(tableLog);
+    uint32_t s2 = read(tableLog);
+    if (cur < 0) return kFail;   // states alone overran the stream: upstream decodes garbage here, never a valid header
     uint32_t n = 0;
     for (;;) {
         if (n + 2 > maxOut) return kFail;
-        { uint32_t const d = dt[s1]; weights[n++] = (uint8_t)d; s1 = (d >> 16) + br.read((d >> 8) & 0xFF); }
-        if (br.left() < 0) { weights[n++] = (uint8_t)dt[s2]; break; }
-        br.refill();
+        { uint32_t const d = dt[s1]; weights[n++] = (uint8_t)d; s1 = (d >> 16) + read((d >> 8) & 0xFF); }
+        if (cur < 0) { weights[n++] = (uint8_t)dt[s2]; break; }
         if (n + 2 > maxOut) return kFail;
-        { uint32_t const d = dt[s2]; weights[n++] = (uint8_t)d; s2 = (d >> 16) + br.read((d >> 8) & 0xFF); }
-        if (br.left() < 0) { weights[n++] = (uint8_t)dt[s1]; break; }
-        br.refill();
+        { uint32_t const d = dt[s2]; weights[n++] = (uint8_t)d; s2 = (d >> 16) + read((d >> 8) & 0xFF); }
+        if (cur < 0) { weights[n++] = (uint8_t)dt[s1]; break; }
     }
     return n;
 }
@@ -1223,13 +1233,16 @@ DEVI void grp_build_seq_table(int t, uint32_t* cells, const int16_t* norm, uint3
 // value of the lane D places lower in the same row of 16 lanes (own value where there is none)
 template <int D>
 DEVI uint32_t row_up(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x110 + D, 0xF, 0xF, false); }
+// quad permute: lane i of every quad takes the value of lane (QP >> 2 i) & 3 of the quad
+template <int QP>
+DEVI uint32_t quad_perm(uint32_t x) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, QP, 0xF, 0xF, true); }
 // value of lane L of the own quad (4 consecutive lanes)
 template <int L>
 DEVI uint32_t quad_lane(uint32_t x) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, L * 0x55, 0xF, 0xF, true); }
 // lane 15 - i of the row (row_mirror): the first lane of a row receives the last lane's value
 DEVI uint32_t row_last_to_first(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x140, 0xF, 0xF, false); }
 constexpr int kSeqJobs = 16;                // jobs (blocks) per workgroup
-constexpr int kSeqThreads = 64 * 5;         // wave 0: the 16 serial chains, one per lane; waves 1-4: 16 lanes per job
+constexpr int kSeqThreads = 64 * 5;         // wave 0: the serial chains, four lanes per job; waves 1-4: helpers, 16 lanes per job
 constexpr uint32_t kSeqRound = 64;          // sequences per round
 constexpr uint32_t kWinUnits = 128;         // circular window of the bitstream, 16-byte units (+ 1 mirror unit)
 constexpr uint32_t kWinAhead = 80;          // units kept loaded below the cursor of the round before last
@@ -1320,7 +1333,7 @@ __global__ __launch_bounds__(kSeqThreads) void k_sequences(BatchParams p)
 
     // ---------------- helper side set-up (waves 1-4): tables, window, per-block constants
     uint32_t const gl = lane & 15, lead = lane & ~15u;
-    bool const helper = wave != 0;
+    bool const chain = wave == 0, helper = wave != 0;
     uint32_t const slot = helper ? (wave - 1) * 4 + (lane >> 4) : (lane >> 2);       // block slot inside the workgroup
     uint32_t const role = lane & 3;            // chain wave: which of a block's four chain lanes this is (LL, ML, OF, cursor)
     uint32_t const job = blockIdx.x * kSeqJobs + slot;
@@ -1450,7 +1463,7 @@ __global__ __launch_bounds__(kSeqThreads) void k_sequences(BatchParams p)
     typedef const __attribute__((address_space(3))) uint32_t* lds_u32;
     typedef __attribute__((address_space(3))) uint32_t* lds_u32w;
     uint32_t const tabL = (uint32_t)(uintptr_t)(lds_u32)(role == 0 ? tLL : role == 1 ? tML : tOF);    // LDS byte address of this lane's table
-    if (!helper) {
+    if (chain) {
         SeqCtl const c = ctl[slot];
         if (!c.fail) {
             remaining = c.nbSeq;
@@ -1464,7 +1477,8 @@ __global__ __launch_bounds__(kSeqThreads) void k_sequences(BatchParams p)
             Q -= logLL + logOF + logML;
         }
     }
-    uint32_t const maskML = role >= 1 ? 0xFFFFFFFFu : 0u, maskOF = role >= 2 ? 0xFFFFFFFFu : 0u;
+
+    uint32_t const mask1 = role >= 1 ? 0xFFFFFFFFu : 0u, mask2 = role >= 2 ? 0xFFFFFFFFu : 0u;
 
     // helper-side running state; carried in the group's first lane only: stack after the sequences done so far
     // (relative to the block's incoming stack) and the positions, saturating at 2^31-1 (frames regenerate < 2 GiB,
@@ -1480,7 +1494,7 @@ __global__ __launch_bounds__(kSeqThreads) void k_sequences(BatchParams p)
     for (uint32_t k = 0;; k++) {
         uint32_t const par = k & 1;
         bool const act = activeFlag[par] != 0;
-        if (!helper) {
+        if (chain) {
             // ---- the serial chains, round k
             if (act) {
                 uint32_t n = 0;
@@ -1492,6 +1506,16 @@ __global__ __launch_bounds__(kSeqThreads) void k_sequences(BatchParams p)
                     uint32_t winL = (uint32_t)(uintptr_t)(lds_u32)win;     // LDS byte addresses, opaque to the compiler: keeps the
                     uint32_t ringL = (uint32_t)(uintptr_t)(lds_u32)ring + 4 * role;    // accesses at small immediate offsets of one address
                     asm volatile("" : "+v"(winL), "+v"(ringL));
+                    // Software pipeline: the cell of the next sequence is requested as soon as its state is known, and the
+                    // bookkeeping (ring entry, cursor, window request for the next sequence) runs while that read is in flight.
+                    auto win_read = [&](uint32_t T, uint32_t& a0, uint32_t& a1, uint32_t& a2, uint32_t& a3) {
+                        lds_u32 const w = (lds_u32)(uintptr_t)(winL + 4 * __builtin_amdgcn_ubfe(T, 5, 9));
+                        a0 = w[0]; a1 = w[1]; a2 = w[2]; a3 = w[3];
+                    };
+                    // 96 bits below the cursor (top at Q + 1, so that the state bits of any sequence start inside them)
+                    uint32_t T = Q - 95, a0, a1, a2, a3;
+                    win_read(T, a0, a1, a2, a3);
+                    uint32_t c = *(lds_u32)(uintptr_t)(tabL + 4 * st);
                     for (; i < kSeqRound; i += 4) {
                         if (Q < Qlim) break;
                         // Past the block's last sequence the chain runs on over bits that mean nothing, inside the window
@@ -1499,26 +1523,27 @@ __global__ __launch_bounds__(kSeqThreads) void k_sequences(BatchParams p)
                         // entry n records the cursor after the last real sequence.
 #pragma unroll
                         for (uint32_t j = 0; j < 4; j++) {
-                            // 96 bits below the cursor (top at Q + 1, so that the state bits of any sequence start inside them)
-                            uint32_t const T = Q - 95;
-                            lds_u32 const w = (lds_u32)(uintptr_t)(winL + 4 * __builtin_amdgcn_ubfe(T, 5, 9));
-                            uint32_t const a0 = w[0], a1 = w[1], a2 = w[2], a3 = w[3];
-                            uint32_t const c = *(lds_u32)(uintptr_t)(tabL + 4 * st);
-                            uint32_t const t2 = __builtin_amdgcn_alignbit(a3, a2, T), t1 = __builtin_amdgcn_alignbit(a2, a1, T), t0 = __builtin_amdgcn_alignbit(a1, a0, T);
                             // sum of the block's three cells: bit counts of the sequence
                             uint32_t const S = quad_lane<0>(c) + quad_lane<1>(c) + quad_lane<2>(c);
                             uint32_t const nEx = __builtin_amdgcn_ubfe(S, 19, 6);
+                            // state bits, order LL, ML, OF (:1220-1225): this lane's lie under those of the tables before it
+                            uint32_t const n = cell_nbBits(c);
+                            uint32_t const before = n + (quad_perm<0x90>(n) & mask1) + (quad_perm<0x40>(n) & mask2);   // + the lane below, + two lanes below
+                            uint32_t const t2 = __builtin_amdgcn_alignbit(a3, a2, T), t1 = __builtin_amdgcn_alignbit(a2, a1, T), t0 = __builtin_amdgcn_alignbit(a1, a0, T);
                             // the 32 bits under the additional bits: bit 63 - nEx of (t2:t1:t0) upwards
                             uint32_t const R = 63u - nEx;
                             bool const up = R >= 32u;
                             uint32_t const h3 = __builtin_amdgcn_alignbit(up ? t2 : t1, up ? t1 : t0, R);
-                            *(lds_u32w)(uintptr_t)(ringL + 16 * (i + j)) = role == 3 ? Q : c;
-                            // state update, order LL, ML, OF (:1220-1225): this lane's bits lie under those of the tables before it;
                             // a cell's nextState has its low nbBits clear
-                            uint32_t const n = cell_nbBits(c);
-                            uint32_t const o = 32u - (quad_lane<0>(n) + (quad_lane<1>(n) & maskML) + (n & maskOF));
-                            st = (c & 0x1FF) | __builtin_amdgcn_ubfe(h3, o, n);
+                            st = (c & 0x1FF) | __builtin_amdgcn_ubfe(h3, 32u - before, n);
+                            uint32_t const cn = *(lds_u32)(uintptr_t)(tabL + 4 * st);
+                            __builtin_amdgcn_sched_barrier(0);
+                            *(lds_u32w)(uintptr_t)(ringL + 16 * (i + j)) = role == 3 ? Q : c;
                             Q -= __builtin_amdgcn_ubfe(S, 12, 7);
+                            T = Q - 95;
+                            win_read(T, a0, a1, a2, a3);
+                            c = cn;
+                            __builtin_amdgcn_sched_barrier(0);
                         }
                     }
                     n = i < remaining ? i : remaining;
@@ -1532,7 +1557,7 @@ __global__ __launch_bounds__(kSeqThreads) void k_sequences(BatchParams p)
                 bool const anyLeft = __any(remaining != 0);
                 if (lane == 0) activeFlag[par ^ 1] = anyLeft ? 1u : 0u;
             }
-        } else if (k >= 1 && !dead) {
+        } else if (helper && k >= 1 && !dead) {
             // ---- helpers, round k-1
             uint32_t const hp = par ^ 1;
             uint2 const pb = pub[hp][slot];
