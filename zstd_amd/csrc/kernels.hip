@@ -993,11 +993,10 @@ __global__ __launch_bounds__(kPackThreads) __attribute__((amdgpu_waves_per_eu(4,
 // Packed decoding cell of a sequence table, laid out so that the SUM of the three cells of a sequence
 // (literal length, match length, offset) carries the bit counts the cursor needs:
 //   bits  0-8   nextState base
-//   bits  9-11  symbol-code bits (LL: 1 bit, ML: 2 bits, OF: none); the sum of three cells stays below 2^12 here
-//   bits 12-18  nbBits + nbAdditionalBits      (sum of three <= 89)
-//   bits 19-24  nbAdditionalBits               (sum of three <= 63)
-//   bits 25-28  nbBits
-//   bits 29-31  symbol-code bits, upper part
+//   bits  9-13  symbol-code bits (LL: code mod 16, ML: code mod 32, OF: none)
+//   bits 14-17  nbBits (<= 9)                  (the low 19 bits of three cells sum to less than 2^19)
+//   bits 19-25  nbBits + nbAdditionalBits      (sum of three <= 89)
+//   bits 26-31  16 (LL, ML) or 31 (OF) - nbAdditionalBits: the sum of three is 63 - (additional bits of the sequence)
 // The code bits hold code mod 16 (LL) or code mod 32 (ML); together with nbAdditionalBits they identify the
 // code (LL codes 0-15 and ML codes 0-31 have no additional bits, the higher ones are told apart by theirs).
 // An offset code equals its nbAdditionalBits.  The base value of a code comes from a small LDS side table.
@@ -1005,20 +1004,19 @@ enum { T_LL = 0, T_OF = 1, T_ML = 2 };
 DEVI uint32_t seq_cell(int t, uint32_t nextState, uint32_t nbBits, uint32_t addBits, uint32_t code)
 {
     uint32_t const low = t == T_LL ? (code & 15u) : t == T_ML ? (code & 31u) : 0u;
-    uint32_t const sl = t == T_LL ? 1u : t == T_ML ? 2u : 0u;
-    return nextState | ((low & ((1u << sl) - 1u)) << 9) | ((nbBits + addBits) << 12) | (addBits << 19) | (nbBits << 25) | ((low >> sl) << 29);
+    return nextState | (low << 9) | (nbBits << 14) | ((nbBits + addBits) << 19) | (((t == T_OF ? 31u : 16u) - addBits) << 26);
 }
-DEVI uint32_t cell_addBits(uint32_t c) { return __builtin_amdgcn_ubfe(c, 19, 6); }
-DEVI uint32_t cell_nbBits(uint32_t c) { return __builtin_amdgcn_ubfe(c, 25, 4); }
+DEVI uint32_t cell_addBits(int t, uint32_t c) { return (t == T_OF ? 31u : 16u) - (c >> 26); }
+DEVI uint32_t cell_nbBits(uint32_t c) { return __builtin_amdgcn_ubfe(c, 14, 4); }
 DEVI uint32_t cell_llCode(uint32_t c)
 {
-    uint32_t const low = ((c >> 9) & 1u) | ((c >> 29) << 1), a = cell_addBits(c);
+    uint32_t const low = (c >> 9) & 15u, a = cell_addBits(T_LL, c);
     return low + (a == 0 ? 0u : a >= 13 ? 32u : 16u);
 }
 DEVI uint32_t cell_mlCode(uint32_t c)
 {
-    uint32_t const low = ((c >> 9) & 3u) | ((c >> 29) << 2);
-    return low + (cell_addBits(c) ? 32u : 0u);
+    uint32_t const low = (c >> 9) & 31u;
+    return low + (cell_addBits(T_ML, c) ? 32u : 0u);
 }
 
 __constant__ uint32_t c_LL_base[36] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18, 20, 22, 24, 28, 32, 40,
@@ -1478,7 +1476,8 @@ __global__ __launch_bounds__(kSeqThreads) void k_sequences(BatchParams p)
         }
     }
 
-    uint32_t const mask1 = role >= 1 ? 0xFFFFFFFFu : 0u, mask2 = role >= 2 ? 0xFFFFFFFFu : 0u;
+    uint32_t mask1 = role >= 1 ? 0xFFFFFFFFu : 0u, mask2 = role >= 2 ? 0xFFFFFFFFu : 0u;
+    asm volatile("" : "+v"(mask1), "+v"(mask2));       // plain data to the compiler: an AND with a DPP operand, not a select
 
     // helper-side running state; carried in the group's first lane only: stack after the sequences done so far
     // (relative to the block's incoming stack) and the positions, saturating at 2^31-1 (frames regenerate < 2 GiB,
@@ -1524,22 +1523,25 @@ __global__ __launch_bounds__(kSeqThreads) void k_sequences(BatchParams p)
 #pragma unroll
                         for (uint32_t j = 0; j < 4; j++) {
                             // sum of the block's three cells: bit counts of the sequence
-                            uint32_t const S = quad_lane<0>(c) + quad_lane<1>(c) + quad_lane<2>(c);
-                            uint32_t const nEx = __builtin_amdgcn_ubfe(S, 19, 6);
+                            uint32_t S = quad_lane<0>(c) + quad_lane<1>(c);
+                            asm volatile("" : "+v"(S));            // (two additions with a DPP operand each, not three moves and an add3)
+                            S += quad_lane<2>(c);
                             // state bits, order LL, ML, OF (:1220-1225): this lane's lie under those of the tables before it
                             uint32_t const n = cell_nbBits(c);
                             uint32_t const before = n + (quad_perm<0x90>(n) & mask1) + (quad_perm<0x40>(n) & mask2);   // + the lane below, + two lanes below
+                            uint32_t const o = 32u - before;
+                            // the 32 bits under the additional bits: bit R = 63 - (their number) of (t2:t1:t0) upwards
+                            uint32_t const R = S >> 26;
+                            bool const up = (int32_t)S < 0;         // R >= 32
+                            __builtin_amdgcn_sched_barrier(0);      // (what needs the cell only comes first: the window words were requested after it)
                             uint32_t const t2 = __builtin_amdgcn_alignbit(a3, a2, T), t1 = __builtin_amdgcn_alignbit(a2, a1, T), t0 = __builtin_amdgcn_alignbit(a1, a0, T);
-                            // the 32 bits under the additional bits: bit 63 - nEx of (t2:t1:t0) upwards
-                            uint32_t const R = 63u - nEx;
-                            bool const up = R >= 32u;
                             uint32_t const h3 = __builtin_amdgcn_alignbit(up ? t2 : t1, up ? t1 : t0, R);
                             // a cell's nextState has its low nbBits clear
-                            st = (c & 0x1FF) | __builtin_amdgcn_ubfe(h3, 32u - before, n);
+                            st = (c & 0x1FF) | __builtin_amdgcn_ubfe(h3, o, n);
                             uint32_t const cn = *(lds_u32)(uintptr_t)(tabL + 4 * st);
                             __builtin_amdgcn_sched_barrier(0);
                             *(lds_u32w)(uintptr_t)(ringL + 16 * (i + j)) = role == 3 ? Q : c;
-                            Q -= __builtin_amdgcn_ubfe(S, 12, 7);
+                            Q -= __builtin_amdgcn_ubfe(S, 19, 7);
                             T = Q - 95;
                             win_read(T, a0, a1, a2, a3);
                             c = cn;
@@ -1584,7 +1586,7 @@ __global__ __launch_bounds__(kSeqThreads) void k_sequences(BatchParams p)
                     bool const valid = i < n;
                     uint32_t tHi, tLo;
                     peek64c(win, Qs, tHi, tLo);
-                    uint32_t const n1 = cell_addBits(cOF), n2 = cell_addBits(cML), n3 = cell_addBits(cLL);
+                    uint32_t const n1 = cell_addBits(T_OF, cOF), n2 = cell_addBits(T_ML, cML), n3 = cell_addBits(T_LL, cLL);
                     uint32_t const ofRaw = take(tHi, 0, n1);
                     uint32_t const h1 = shl_hi(tHi, tLo, n1);
                     uint32_t const llCode = cell_llCode(cLL), mlCode = cell_mlCode(cML);
