@@ -994,8 +994,9 @@ __global__ __launch_bounds__(kPackThreads) __attribute__((amdgpu_waves_per_eu(4,
 // (literal length, match length, offset) carries the bit counts the cursor needs:
 //   bits  0-8   nextState base
 //   bits  9-13  symbol-code bits (LL: code mod 16, ML: code mod 32, OF: none)
-//   bits 14-17  nbBits (<= 9)                  (the low 19 bits of three cells sum to less than 2^19)
-//   bits 19-25  nbBits + nbAdditionalBits      (sum of three <= 89)
+//   bits 14-18  (32 - nbBits) mod 32: summed over the cells of the tables read before and this one, mod 32, it is where
+//               this table's bits start in the 32 bits that follow the additional bits
+//   bits 21-25  nbBits (<= 9; the low 19 bits of three cells sum to less than 2^21, the sum of three here is <= 26)
 //   bits 26-31  16 (LL, ML) or 31 (OF) - nbAdditionalBits: the sum of three is 63 - (additional bits of the sequence)
 // The code bits hold code mod 16 (LL) or code mod 32 (ML); together with nbAdditionalBits they identify the
 // code (LL codes 0-15 and ML codes 0-31 have no additional bits, the higher ones are told apart by theirs).
@@ -1004,10 +1005,10 @@ enum { T_LL = 0, T_OF = 1, T_ML = 2 };
 DEVI uint32_t seq_cell(int t, uint32_t nextState, uint32_t nbBits, uint32_t addBits, uint32_t code)
 {
     uint32_t const low = t == T_LL ? (code & 15u) : t == T_ML ? (code & 31u) : 0u;
-    return nextState | (low << 9) | (nbBits << 14) | ((nbBits + addBits) << 19) | (((t == T_OF ? 31u : 16u) - addBits) << 26);
+    return nextState | (low << 9) | (((32u - nbBits) & 31u) << 14) | (nbBits << 21) | (((t == T_OF ? 31u : 16u) - addBits) << 26);
 }
 DEVI uint32_t cell_addBits(int t, uint32_t c) { return (t == T_OF ? 31u : 16u) - (c >> 26); }
-DEVI uint32_t cell_nbBits(uint32_t c) { return __builtin_amdgcn_ubfe(c, 14, 4); }
+DEVI uint32_t cell_nbBits(uint32_t c) { return __builtin_amdgcn_ubfe(c, 21, 4); }
 DEVI uint32_t cell_llCode(uint32_t c)
 {
     uint32_t const low = (c >> 9) & 15u, a = cell_addBits(T_LL, c);
@@ -1499,8 +1500,9 @@ __global__ __launch_bounds__(kSeqThreads) void k_sequences(BatchParams p)
                 uint32_t n = 0;
                 uint32_t* const ring = ring0 + par * 4 * kSeqRound;
                 if (remaining) {
-                    // lowest bit the window is known to hold, plus what 4 sequences and a 96-bit peek can reach
-                    uint32_t const Qlim = ((e2 >> 7) - kWinAhead) * 128 + 96 + 4 * 89;
+                    // lowest bit the window is known to hold, plus what 8 sequences and a 96-bit peek can reach (as a bound on
+                    // T = cursor - 95, the variable the loop carries)
+                    uint32_t const Tlim = ((e2 >> 7) - kWinAhead) * 128 + 96 + 8 * 89 - 95;
                     uint32_t i = 0;
                     uint32_t winL = (uint32_t)(uintptr_t)(lds_u32)win;     // LDS byte addresses, opaque to the compiler: keeps the
                     uint32_t ringL = (uint32_t)(uintptr_t)(lds_u32)ring + 4 * role;    // accesses at small immediate offsets of one address
@@ -1515,21 +1517,21 @@ __global__ __launch_bounds__(kSeqThreads) void k_sequences(BatchParams p)
                     uint32_t T = Q - 95, a0, a1, a2, a3;
                     win_read(T, a0, a1, a2, a3);
                     uint32_t c = *(lds_u32)(uintptr_t)(tabL + 4 * st);
-                    for (; i < kSeqRound; i += 4) {
-                        if (Q < Qlim) break;
+                    for (; i < kSeqRound; i += 8) {
+                        if (T < Tlim) break;
                         // Past the block's last sequence the chain runs on over bits that mean nothing, inside the window
                         // and inside the tables (a state never leaves its table); those ring entries are ignored, and
-                        // entry n records the cursor after the last real sequence.
+                        // entry n records the cursor (less 95) after the last real sequence.
 #pragma unroll
-                        for (uint32_t j = 0; j < 4; j++) {
+                        for (uint32_t j = 0; j < 8; j++) {
                             // sum of the block's three cells: bit counts of the sequence
                             uint32_t S = quad_lane<0>(c) + quad_lane<1>(c);
                             asm volatile("" : "+v"(S));            // (two additions with a DPP operand each, not three moves and an add3)
                             S += quad_lane<2>(c);
                             // state bits, order LL, ML, OF (:1220-1225): this lane's lie under those of the tables before it
                             uint32_t const n = cell_nbBits(c);
-                            uint32_t const before = n + (quad_perm<0x90>(n) & mask1) + (quad_perm<0x40>(n) & mask2);   // + the lane below, + two lanes below
-                            uint32_t const o = 32u - before;
+                            uint32_t const ng = __builtin_amdgcn_ubfe(c, 14, 5);
+                            uint32_t const o = ng + (quad_perm<0x90>(ng) & mask1) + (quad_perm<0x40>(ng) & mask2);   // + the lane below, + two lanes below; mod 32
                             // the 32 bits under the additional bits: bit R = 63 - (their number) of (t2:t1:t0) upwards
                             uint32_t const R = S >> 26;
                             bool const up = (int32_t)S < 0;         // R >= 32
@@ -1540,16 +1542,16 @@ __global__ __launch_bounds__(kSeqThreads) void k_sequences(BatchParams p)
                             st = (c & 0x1FF) | __builtin_amdgcn_ubfe(h3, o, n);
                             uint32_t const cn = *(lds_u32)(uintptr_t)(tabL + 4 * st);
                             __builtin_amdgcn_sched_barrier(0);
-                            *(lds_u32w)(uintptr_t)(ringL + 16 * (i + j)) = role == 3 ? Q : c;
-                            Q -= __builtin_amdgcn_ubfe(S, 19, 7);
-                            T = Q - 95;
+                            uint32_t const Tprev = T;
+                            T = T + R - 63u - __builtin_amdgcn_ubfe(S, 21, 5);       // additional bits: 63 - R
                             win_read(T, a0, a1, a2, a3);
+                            *(lds_u32w)(uintptr_t)(ringL + 16 * (i + j)) = role == 3 ? Tprev : c;
                             c = cn;
                             __builtin_amdgcn_sched_barrier(0);
                         }
                     }
                     n = i < remaining ? i : remaining;
-                    if (n < i) Q = ring[4 * n + 3];
+                    Q = (n < i ? ring[4 * n + 3] : T) + 95;
                     remaining -= n;
                     // the stream ran dry: some sequence of this round is flagged by the helpers, nothing after it counts
                     if ((int)Q < dryBelow) remaining = 0;
@@ -1582,7 +1584,7 @@ __global__ __launch_bounds__(kSeqThreads) void k_sequences(BatchParams p)
                 for (int u = 0; u < 4; u++) {
                     uint32_t const i = 4 * gl + u;
                     uint4 const r = *(const uint4*)(ring + 4 * i);
-                    uint32_t const cLL = r.x, cML = r.y, cOF = r.z, Qs = r.w;
+                    uint32_t const cLL = r.x, cML = r.y, cOF = r.z, Qs = r.w + 95;
                     bool const valid = i < n;
                     uint32_t tHi, tLo;
                     peek64c(win, Qs, tHi, tLo);
@@ -1680,7 +1682,7 @@ __global__ __launch_bounds__(kSeqThreads) void k_sequences(BatchParams p)
             }
         }
         wg_barrier();
-        if (!act || k > (1u << 16)) break;     // (every round with work left decodes at least 4 sequences of each unfinished block)
+        if (!act || k > (1u << 16)) break;     // (every round with work left decodes at least 8 sequences of each unfinished block)
     }
     wave_sync();         // the round stores are complete before the end record goes on top of one of them
     if (helper && hasJob && gl == 0) {
