@@ -1324,10 +1324,11 @@ __global__ __launch_bounds__(kSeqThreads) void k_sequences(BatchParams p)
     __shared__ SeqCtl ctl[kSeqJobs];
     __shared__ uint2 pub[2][kSeqJobs];         // per round parity and block: {cursor after the round, sequences decoded in it}
     __shared__ uint32_t activeFlag[2];         // per round parity: some block still has sequences to decode in that round
+    __shared__ uint32_t zeroCell;              // the "table" of a block's fourth chain lane: its cell adds nothing to the sum of the quad
     uint32_t const tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     if (tid < 36) { sLLbase[tid] = c_LL_base[tid]; sLLbits[tid] = c_LL_bits[tid]; }
     if (tid < 53) { sMLbase[tid] = c_ML_base[tid]; sMLbits[tid] = c_ML_bits[tid]; }
-    if (tid == 0) { activeFlag[0] = 1; activeFlag[1] = 0; }
+    if (tid == 0) { activeFlag[0] = 1; activeFlag[1] = 0; zeroCell = 0; }
     wg_barrier();
 
     // ---------------- helper side set-up (waves 1-4): tables, window, per-block constants
@@ -1453,7 +1454,7 @@ __global__ __launch_bounds__(kSeqThreads) void k_sequences(BatchParams p)
     wg_barrier();
 
     // ---------------- chain side set-up (wave 0): four lanes per block, one per table plus one that records the cursor
-    // (it shadows the offset lane).  Every lane keeps one FSE state; what the lanes need of each other's cells comes
+    // (its own "cell" is a zero word).  Every lane keeps one FSE state; what the lanes need of each other's cells comes
     // through DPP quad permutes.
     uint32_t st = 0;                           // this lane's FSE state
     uint32_t Q = 0, e1 = 0, e2 = 0;            // cursor; cursor after the previous round and after the one before
@@ -1461,7 +1462,7 @@ __global__ __launch_bounds__(kSeqThreads) void k_sequences(BatchParams p)
     int dryBelow = 0;                          // a cursor below this is past the stream start by more than the last state update may read
     typedef const __attribute__((address_space(3))) uint32_t* lds_u32;
     typedef __attribute__((address_space(3))) uint32_t* lds_u32w;
-    uint32_t const tabL = (uint32_t)(uintptr_t)(lds_u32)(role == 0 ? tLL : role == 1 ? tML : tOF);    // LDS byte address of this lane's table
+    uint32_t const tabL = (uint32_t)(uintptr_t)(lds_u32)(role == 0 ? tLL : role == 1 ? tML : role == 2 ? tOF : &zeroCell);    // LDS byte address of this lane's table
     if (chain) {
         SeqCtl const c = ctl[slot];
         if (!c.fail) {
@@ -1472,7 +1473,7 @@ __global__ __launch_bounds__(kSeqThreads) void k_sequences(BatchParams p)
             uint32_t const logLL = c.logs & 255, logOF = (c.logs >> 8) & 255, logML = c.logs >> 16;
             uint32_t tHi, tLo;
             peek64c(win, Q, tHi, tLo);
-            st = role == 0 ? take(tHi, 0, logLL) : role == 1 ? take(tHi, logLL + logOF, logML) : take(tHi, logLL, logOF);
+            st = role == 0 ? take(tHi, 0, logLL) : role == 1 ? take(tHi, logLL + logOF, logML) : role == 2 ? take(tHi, logLL, logOF) : 0u;
             Q -= logLL + logOF + logML;
         }
     }
@@ -1525,9 +1526,10 @@ __global__ __launch_bounds__(kSeqThreads) void k_sequences(BatchParams p)
 #pragma unroll
                         for (uint32_t j = 0; j < 8; j++) {
                             // sum of the block's three cells: bit counts of the sequence
-                            uint32_t S = quad_lane<0>(c) + quad_lane<1>(c);
-                            asm volatile("" : "+v"(S));            // (two additions with a DPP operand each, not three moves and an add3)
-                            S += quad_lane<2>(c);
+                            // (the fourth lane's cell is zero and its state stays zero)
+                            uint32_t S = c + quad_perm<0xB1>(c);        // lanes 1 0 3 2
+                            asm volatile("" : "+v"(S));
+                            S += quad_perm<0x4E>(S);                    // lanes 2 3 0 1
                             // state bits, order LL, ML, OF (:1220-1225): this lane's lie under those of the tables before it
                             uint32_t const n = cell_nbBits(c);
                             uint32_t const ng = __builtin_amdgcn_ubfe(c, 14, 5);
