@@ -656,6 +656,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
             uint32_t* const soL = (uint32_t*)(outStage + sl * kSpecRound);
             uintptr_t wbL = 0;
             bool prevActive = false;
+            uint32_t rem = 0;               // the 32 bits below the cursor, of which the top 20 or more are known from the last group
 #ifdef ZG_STAMPS
             uint64_t zA = 0, zB = 0, zC = 0, zR = 0, zS = 0, zG = 0, zZ = 0; uint64_t const z0 = __builtin_readcyclecounter();
 #endif
@@ -701,6 +702,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
                     else {
                         prevActive = true;
                         int const Qbase = (int)(8 * (int64_t)((uintptr_t)myStart - wbL));
+                        if (r == 0) { uint32_t lo; peek64(winL, (uint32_t)(Qbase + cur), rem, lo); }
                         // always the whole round (no lane-dependent exit from the loop): a lane that has met the part ahead, or
                         // failed, decodes on harmlessly inside its window; what it produces past that point is never used
 #pragma unroll
@@ -708,7 +710,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
                             uint32_t const Q = (uint32_t)(Qbase + cur);
                             uint32_t tHi, tLo;
                             peek64(winL, Q, tHi, tLo);
-                            uint32_t const c0 = cells[tHi >> shift];
+                            // (the first code of a group is looked up in what the previous group left of its 64 bits -- at least 20 --
+                            // while the window words of this group are on their way)
+                            uint32_t const c0 = cells[rem >> shift];
                             uint32_t const l0 = c0 >> 8;
                             uint32_t const c1 = cells[shl_hi(tHi, tLo, l0) >> shift];
                             uint32_t const l1 = l0 + (c1 >> 8);
@@ -746,6 +750,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
                             }
                             nDec += 4;
                             cur -= (int)l3;
+                            rem = shl_hi(tHi, tLo, l3);
                             {
                                 bool const open = !met && !failed;
                                 bool const atEnd = open && t == 4;
