@@ -2010,110 +2010,140 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
 
         // One sequence per lane: record = (offset, output position, literal position, litLength), block-relative;
         // lanes past the batch's last sequence read the record after it, whose output position ends the batch.
-        // The records of the next batch are requested before the stores of the current one.
-        uint4 rcN = make_uint4(0, 0, 0, 0), endN = make_uint4(0, 0, 0, 0);
-        if (nValid) {
-            uint32_t const n = nValid < 64 ? nValid : 64;
-            rcN = recs[lane < n ? lane : n];
-            endN = recs[n];
-        }
-        for (uint32_t s0 = 0; s0 < nValid && !ferr; s0 += 64) {
-#ifdef ZG_STAMPS
-            uint64_t const x0 = __builtin_readcyclecounter();
-#endif
-            uint32_t const n = nValid - s0 < 64 ? nValid - s0 : 64;
-            bool const have = lane < n;
-            uint4 const rc = rcN;
-            uint32_t const endY = uni(endN.y), endZ = uni(endN.z);
+        // The loop is software-pipelined: while the loads of a batch are in flight the plan of the next batch is
+        // worked out from its records (requested one batch earlier), and the records of the batch after that are
+        // requested.
+        uint4 rcN = make_uint4(0, 0, 0, 0), rcB = rcN;        // records of the next batch (arrived) and of the one after it (in flight)
+        uint2 endN = make_uint2(0, 0), endB = endN;             // {output position, literal position} of the record that ends those batches
+        auto load_recs = [&](uint32_t s, uint4& rc, uint2& end) {     // records of the batch that starts at sequence s (past the end: the end record)
+            uint32_t const sc = s < nValid ? s : nValid;
+            uint32_t const n2 = nValid - sc < 64 ? nValid - sc : 64;
+            rc = recs[sc + (lane < n2 ? lane : n2)];
+            end = *(const uint2*)((const uint32_t*)(recs + sc + n2) + 1);
+        };
+        // What a batch needs, from its records alone.  Per lane: the sequence's start inside the batch, lengths, offset,
+        // literal position, source position; the rest is the same in every lane.
+        struct Plan {
+            uint32_t start, ll, lstart, off, ml, gcnt, gEnd;
+            int64_t absS;
+            bool have, plain, fastS;
+            uint32_t total, lit0, sumLL, base0, litEnd, err;
+            bool staged;
+        };
+        auto make_plan = [&](uint4 const rc, uint2 const endV, uint32_t const s) -> Plan {
+            Plan q;
+            uint32_t const n = s < nValid ? (nValid - s < 64 ? nValid - s : 64) : 0;
+            q.have = lane < n;
+            uint32_t const endY = uni(endV.x), endZ = uni(endV.y);
             uint32_t const below = wave_next(rc.y);
-            uint32_t const nstart = lane == 63 ? endY : (have ? below : rc.y);
-            uint32_t const bstart = rc.y, lstart = rc.z;
-            uint32_t const ll = have ? rc.w : 0;
-            uint32_t const off = have ? rep_subst(rc.x, rin0, rin1, rin2) : 1;
+            uint32_t const nstart = lane == 63 ? endY : (q.have ? below : rc.y);
+            uint32_t const bstart = rc.y;
+            q.lstart = rc.z;
+            q.ll = q.have ? rc.w : 0;
+            q.off = q.have ? rep_subst(rc.x, rin0, rin1, rin2) : 1;
             // per-sequence checks in the order of ZSTD_execSequenceEnd / ZSTD_execSequence (:896-1008)
             uint32_t code = 0;
-            if (have) {
+            if (q.have) {
                 if (nstart > room) code = E_dstSize_tooSmall;
-                else if ((uint64_t)lstart + ll > litSize) code = E_corruption;
-                else if ((uint64_t)off > bo + bstart + ll + dictN) code = E_corruption;
+                else if ((uint64_t)q.lstart + q.ll > litSize) code = E_corruption;
+                else if ((uint64_t)q.off > bo + bstart + q.ll + dictN) code = E_corruption;
             }
             unsigned long long const bad = __ballot(code != 0);
-            if (bad) { ferr = uni((uint32_t)__shfl(code, __builtin_ctzll(bad))); break; }
-            uint32_t const ml = nstart - bstart - ll;
-            uint32_t const base0 = lane_value(bstart, 0);           // block-relative start of the batch (== pos)
-            uint32_t const start = bstart - base0;
-            uint32_t const total = lane_value(nstart, 63) - base0;
-            int64_t const batchAbs = (int64_t)(bo + pos);
+            q.err = bad ? uni((uint32_t)__shfl(code, __builtin_ctzll(bad))) : 0u;
+            q.ml = nstart - bstart - q.ll;
+            q.base0 = lane_value(bstart, 0);           // block-relative start of the batch
+            q.start = bstart - q.base0;
+            q.total = lane_value(nstart, 63) - q.base0;
+            q.litEnd = lane_value(q.lstart + q.ll, 63);
+            int64_t const batchAbs = (int64_t)(bo + q.base0);
             // A match is "plain" when its source lies wholly before the batch, on one side of the dictionary
             // boundary, and does not overlap its destination: a copy from memory.  The others (about 1 match in 12 on
             // text) depend on bytes of the batch itself, or repeat a pattern.
-            int64_t const ms = (int64_t)(start + ll) - (int64_t)off;          // batch-relative source start
-            int64_t const absS = batchAbs + ms;
-            bool const plain = have && off >= ml && ms + (int64_t)ml <= 0 && (absS >= 0 || absS + (int64_t)ml <= 0);
+            int64_t const ms = (int64_t)(q.start + q.ll) - (int64_t)q.off;          // batch-relative source start
+            q.absS = batchAbs + ms;
+            q.plain = q.have && q.off >= q.ml && ms + (int64_t)q.ml <= 0 && (q.absS >= 0 || q.absS + (int64_t)q.ml <= 0);
             // Batches of short runs (the usual case) are assembled in LDS; there a plain match is fetched as 16 or 32
             // bytes whatever its length, which must stay inside the frame's output area or the dictionary.
-            uint32_t const lit0 = lane_value(lstart, 0);
-            uint32_t const sumLL = endZ - lit0;          // the literals of a batch are contiguous
-            int64_t const fetchEnd = absS + (ml > 16 ? 32 : 16);
-            bool const fastS = plain && (absS >= 0 ? fetchEnd <= (int64_t)cap : fetchEnd <= 0);
-            uint32_t const slowS = (have && !fastS) ? ml : 0;
+            q.lit0 = lane_value(q.lstart, 0);
+            q.sumLL = endZ - q.lit0;          // the literals of a batch are contiguous
+            int64_t const fetchEnd = q.absS + (q.ml > 16 ? 32 : 16);
+            q.fastS = q.plain && (q.absS >= 0 ? fetchEnd <= (int64_t)cap : fetchEnd <= 0);
+            uint32_t const slowS = (q.have && !q.fastS) ? q.ml : 0;
             // of a match handled in LDS, the leading bytes whose source lies before the batch come from memory, one per lane
-            int64_t const lead = -ms < (int64_t)(ml < off ? ml : off) ? -ms : (int64_t)(ml < off ? ml : off);
-            uint32_t const gcnt = (slowS && lead > 0) ? (uint32_t)lead : 0u;
-            uint32_t const gEnd = wave_incl_scan(gcnt);
-            bool const staged = total <= kOutStage && sumLL <= kLitStage && lane_value(gEnd, 63) <= 64 && !__any(ll > 32 || (plain && ml > 32));
+            int64_t const lead = -ms < (int64_t)(q.ml < q.off ? q.ml : q.off) ? -ms : (int64_t)(q.ml < q.off ? q.ml : q.off);
+            q.gcnt = (slowS && lead > 0) ? (uint32_t)lead : 0u;
+            q.gEnd = wave_incl_scan(q.gcnt);
+            q.staged = q.total <= kOutStage && q.sumLL <= kLitStage && lane_value(q.gEnd, 63) <= 64 && !__any(q.ll > 32 || (q.plain && q.ml > 32));
+            return q;
+        };
+        Plan pl = {};
+        if (nValid) {
+            load_recs(0, rcN, endN);
+            pl = make_plan(rcN, endN, 0);
+            load_recs(64, rcN, endN);
+        }
+        for (uint32_t s0 = 0; s0 < nValid; s0 += 64) {
+#ifdef ZG_STAMPS
+            uint64_t const x0 = __builtin_readcyclecounter();
+#endif
+            if (pl.err) { ferr = pl.err; break; }
+            load_recs(s0 + 128, rcB, endB);      // ahead of the batch's own loads: the wait for those covers it
+            bool const have = pl.have, plain = pl.plain, fastS = pl.fastS, staged = pl.staged;
+            uint32_t const start = pl.start, ll = pl.ll, lstart = pl.lstart, off = pl.off, ml = pl.ml, gcnt = pl.gcnt, gEnd = pl.gEnd;
+            uint32_t const total = pl.total, lit0 = pl.lit0, sumLL = pl.sumLL, base0 = pl.base0;
+            int64_t const absS = pl.absS;
+            int64_t const batchAbs = (int64_t)(bo + base0);
+            uint32_t const slowS = (have && !fastS) ? ml : 0;
             const uint8_t* const matSrc = absS >= 0 ? fdst + absS : dictEnd + absS;
 #ifdef ZG_STAMPS
             uint64_t const x1 = __builtin_readcyclecounter();
             uint64_t x2 = x1, x3 = x1, x4 = x1;
 #endif
-            if (s0 + 64 < nValid) {     // the next batch's records
-                uint32_t const n2 = nValid - s0 - 64 < 64 ? nValid - s0 - 64 : 64;
-                rcN = recs[s0 + 64 + (lane < n2 ? lane : n2)];
-                endN = recs[s0 + 64 + n2];
-            }
-            if (staged) {
-                // Global accesses per batch: one coalesced literal load, one or two 16-byte loads per plain match,
-                // single bytes for source bytes before the batch of the other matches, and the whole-wave output stores.
-                uint32_t const fastLen = fastS ? ml : 0;
-                // ---- all global loads of the batch
-                const uint8_t* const litG = litBase + lit0;
-                uint32_t const litFull = sumLL >> 4, litTail = sumLL & 15;
-                uint4 litV = make_uint4(rleFill, rleFill, rleFill, rleFill);
-                uint8_t litT = (uint8_t)rleFill;
-                if (!litRle) {
-                    if (lane < litFull) __builtin_memcpy(&litV, litG + 16 * lane, 16);
-                    if (lane < litTail) litT = litG[16 * litFull + lane];
-                }
-                uint4 mv0 = make_uint4(0, 0, 0, 0), mv1 = mv0;
-                if (fastLen) __builtin_memcpy(&mv0, matSrc, 16);
-                if (fastLen > 16) __builtin_memcpy(&mv1, matSrc + 16, 16);
-                uint32_t gdst = 0xFFFFFFFFu;
-                uint8_t gv = 0;
-                {
-                    const uint8_t* gsrc = fdst;
-                    unsigned long long gm = __ballot(gcnt != 0);
-                    while (gm) {
-                        int const w = __builtin_ctzll(gm);
-                        gm &= gm - 1;
-                        uint32_t const cnt = lane_value(gcnt, w), first = lane_value(gEnd, w) - cnt, d0 = lane_value(start + ll, w);
-                        int64_t const absW = (int64_t)(((uint64_t)lane_value((uint32_t)((uint64_t)absS >> 32), w) << 32) | lane_value((uint32_t)absS, w));
-                        uint32_t const j = lane - first;
-                        if (j < cnt) {
-                            int64_t const abs = absW + j;
-                            gdst = d0 + j;
-                            gsrc = abs >= 0 ? fdst + abs : dictEnd + abs;
-                        }
+            // ---- all global loads of a batch assembled in LDS: one coalesced literal load, one or two 16-byte loads per
+            // plain match, single bytes for source bytes before the batch of the other matches
+            // Every lane issues every load, on a harmless address (the block's records) when it has nothing to fetch: a fixed
+            // number of loads in flight lets the waits further down be counted instead of draining everything.
+            uint32_t const fastLen = (staged && fastS) ? ml : 0;
+            uint32_t const litFull = sumLL >> 4, litTail = sumLL & 15;
+            const uint8_t* const safe = (const uint8_t*)recs;
+            const uint8_t* const litG = litBase + lit0;
+            bool const stagedLit = staged && !litRle;
+            uint4 litV, mv0, mv1;
+            __builtin_memcpy(&litV, (stagedLit && lane < litFull) ? litG + 16 * lane : safe, 16);
+            uint8_t const litT = *((stagedLit && lane < litTail) ? litG + 16 * litFull + lane : safe);
+            __builtin_memcpy(&mv0, fastLen ? matSrc : safe, 16);
+            __builtin_memcpy(&mv1, fastLen > 16 ? matSrc + 16 : safe, 16);
+            uint32_t gdst = 0xFFFFFFFFu;
+            const uint8_t* gsrc = safe;
+            {
+                unsigned long long gm = staged ? __ballot(gcnt != 0) : 0ull;
+                while (gm) {
+                    int const w = __builtin_ctzll(gm);
+                    gm &= gm - 1;
+                    uint32_t const cnt = lane_value(gcnt, w), first = lane_value(gEnd, w) - cnt, d0 = lane_value(start + ll, w);
+                    int64_t const absW = (int64_t)(((uint64_t)lane_value((uint32_t)((uint64_t)absS >> 32), w) << 32) | lane_value((uint32_t)absS, w));
+                    uint32_t const j = lane - first;
+                    if (j < cnt) {
+                        int64_t const abs = absW + j;
+                        gdst = d0 + j;
+                        gsrc = abs >= 0 ? fdst + abs : dictEnd + abs;
                     }
-                    if (gdst != 0xFFFFFFFFu) gv = *gsrc;
                 }
+            }
+            uint8_t const gv = *gsrc;
 #ifdef ZG_STAMPS
-                x2 = __builtin_readcyclecounter();
+            x2 = __builtin_readcyclecounter();
 #endif
+            // ---- while those are in flight: the next batch's plan
+            Plan const plN = make_plan(rcN, endN, s0 + 64);
+            if (staged) {
                 // ---- literals and fetched match bytes into LDS, then every run into its place in the output stage
                 lds_sync();       // the previous batch's reads of the stages are done
-                if (lane < litFull || litRle) *(uint4*)(litStage + 16 * lane) = litV;
-                if (lane < litTail) litStage[16 * litFull + lane] = litT;
+                if (litRle) *(uint4*)(litStage + 16 * lane) = make_uint4(rleFill, rleFill, rleFill, rleFill);
+                else {
+                    if (lane < litFull) *(uint4*)(litStage + 16 * lane) = litV;
+                    if (lane < litTail) litStage[16 * litFull + lane] = litT;
+                }
                 if (fastLen) *(uint4*)(matStage + 32 * lane) = mv0;
                 if (fastLen > 16) *(uint4*)(matStage + 32 * lane + 16) = mv1;
 #ifdef ZG_STAMPS
@@ -2145,7 +2175,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
                 lds_sync();
                 // ---- the batch's output, contiguous: 16 bytes per lane, then the last bytes one per lane
                 {
-                    uint8_t* const d0 = fdst + bo + pos;
+                    uint8_t* const d0 = fdst + bo + base0;
                     uint32_t const full = total >> 4, tail = total & 15;
                     for (uint32_t u = lane; u < full; u += 64) {
                         uint4 const x = *(const uint4*)(outStage + 16 * u);
@@ -2159,18 +2189,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
             } else {
                 // Long runs: straight from memory to memory; the other matches byte by byte through the batch's
                 // sequence table in LDS.
-                uint32_t const fastLen = plain ? ml : 0, slowLen = (have && !plain) ? ml : 0;
+                uint32_t const fastLenD = plain ? ml : 0, slowLen = (have && !plain) ? ml : 0;
                 uint32_t const slowEnd = wave_incl_scan(slowLen);
                 uint32_t const slowTotal = lane_value(slowEnd, 63);
                 lds_sync();       // previous LDS reads done
                 sStart[lane] = start; sLL[lane] = ll; sOff[lane] = off; sLit[lane] = lstart; sSlowEnd[lane] = slowEnd;
                 if (lane == 63) sStart[64] = total;
                 lds_sync();
-                exec_batch_direct(sStart, sLL, sOff, sLit, sSlowEnd, litBase, fdst, dictEnd, batchAbs, litRle, fdst + bo + bstart,
-                                  litRle ? litBase : litBase + lstart, matSrc, ll, fastLen, slowTotal, fdst + bo + pos, lane);
+                exec_batch_direct(sStart, sLL, sOff, sLit, sSlowEnd, litBase, fdst, dictEnd, batchAbs, litRle, fdst + bo + base0 + start,
+                                  litRle ? litBase : litBase + lstart, matSrc, ll, fastLenD, slowTotal, fdst + bo + base0, lane);
             }
-            pos += total;
-            litPos = lane_value(lstart + ll, 63);
+            pos = (uint64_t)base0 + total;
+            litPos = pl.litEnd;
 #ifdef ZG_STAMPS
             if (p.dbg && lane == 0) {
                 uint64_t const x5 = __builtin_readcyclecounter();
@@ -2178,6 +2208,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
                 g[0] += x1 - x0; g[1] += x2 - x1; g[2] += x3 - x2; g[3] += x4 - x3; g[4] += x5 - x4; g[5] += 1; g[6] += __builtin_popcountll(__ballot(slowS != 0)); g[7] += staged ? 1 : 0;
             }
 #endif
+            pl = plN;
+            rcN = rcB; endN = endB;
         }
         if (ferr) break;
         if (nbSeq && nValid < nbSeq) { ferr = E_corruption; break; }
