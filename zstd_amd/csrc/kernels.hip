@@ -2018,8 +2018,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
         auto load_recs = [&](uint32_t s, uint4& rc, uint2& end) {     // records of the batch that starts at sequence s (past the end: the end record)
             uint32_t const sc = s < nValid ? s : nValid;
             uint32_t const n2 = nValid - sc < 64 ? nValid - sc : 64;
-            rc = recs[sc + (lane < n2 ? lane : n2)];
-            end = *(const uint2*)((const uint32_t*)(recs + sc + n2) + 1);
+            // (read once: no need to keep them in the caches, which the match sources want)
+            typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+            typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+            v4u const r4 = __builtin_nontemporal_load((const v4u*)(recs + sc + (lane < n2 ? lane : n2)));
+            v2u const e2 = __builtin_nontemporal_load((const v2u*)((const uint32_t*)(recs + sc + n2) + 1));
+            rc = make_uint4(r4.x, r4.y, r4.z, r4.w);
+            end = make_uint2(e2.x, e2.y);
         };
         // What a batch needs, from its records alone.  Per lane: the sequence's start inside the batch, lengths, offset,
         // literal position, source position; the rest is the same in every lane.
