@@ -133,6 +133,19 @@ zstdgpu_batch* zstdgpu_batch_create(zstdgpu_ctx* ctx, const void* hostSrc, size_
 zstdgpu_batch* zstdgpu_batch_create_from_frames(zstdgpu_ctx* ctx, const void* hostSrc, size_t srcBytes,
                                                 const zstdgpu_frame_in* in, uint32_t nFrames,
                                                 const zstdgpu_ddict* ddict);
+/* The same batch built from a source that is already in DEVICE memory: the frame headers
+ * (ZSTD_getFrameHeader_advanced, decompress/zstd_decompressf.pas:281-395), the block headers (ZSTD_getcBlockSize,
+ * decompress/zstd_decompress_block.pas:190-207; the loop of ZSTD_findFrameSizeInfo, decompress/zstd_decompressf.pas:566-639)
+ * and the literal / sequence section headers (decompress/zstd_decompress_block.pas:243-274, :333-400, :708-742) are
+ * walked by device kernels, one lane per frame; no host copy of the compressed bytes is needed.  `in` is a host array.
+ * The descriptors are identical to those of the host walk.  Synchronous (two small device-to-host copies size the
+ * scratch buffers).  `devSrc` must hold the same bytes when the batch is decoded.  Returns NULL on failure. */
+zstdgpu_batch* zstdgpu_batch_create_on_device(zstdgpu_ctx* ctx, const void* devSrc, size_t srcBytes,
+                                              const zstdgpu_frame_in* in, uint32_t nFrames,
+                                              const zstdgpu_ddict* ddict);
+/* Test hook: a 64-bit digest of the batch's descriptor arrays (blocks, frames, job lists); the host walk and the
+ * device walk over the same input give the same value. */
+uint64_t zstdgpu_batch_descriptorDigest(zstdgpu_batch* batch);
 /* Destroy a batch before its context.  The two large scratch buffers (literals, sequence records) go back to the
  * context and are handed to the next batch that fits them, so a steady stream of batches allocates once. */
 void zstdgpu_batch_destroy(zstdgpu_batch* batch);

@@ -217,3 +217,87 @@ def test_truncated_capacity_and_isolated_errors(dctx):
     o1 = int(fin[1]["dstOff"])
     assert (out[o1 + 131071:o2] == 0xAA).all()
     b.close()
+
+
+# ------------------------------------------------------------------ descriptors built on the device
+def _both_walks(dctx, frames, caps, ddict=None, extra_in=None):
+    """The same input through the host walk and the device walk: descriptor digests, verdicts and bytes must agree."""
+    import torch
+    src, fin, dst_bytes = api.pack_frames(frames, caps)
+    if extra_in is not None:
+        fin = np.concatenate([fin, np.array(extra_in, dtype=api.FRAME_IN_DTYPE)])
+    d_src = dev(src)
+    bh = api.Batch(dctx, src, fin, ddict)
+    bd = api.Batch(dctx, None, fin, ddict, dev_src_ptr=d_src.data_ptr(), dev_src_bytes=src.nbytes)
+    assert bd.n_blocks == bh.n_blocks
+    assert bd.src_bytes == bh.src_bytes
+    assert bd.descriptor_digest == bh.descriptor_digest
+    outs = []
+    for b in (bh, bd):
+        d_dst = torch.zeros(max(dst_bytes, 1), dtype=torch.uint8, device="cuda")
+        b.decode(d_src.data_ptr(), d_dst.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        outs.append((b.status().copy(), d_dst.cpu().numpy()))
+        b.close()
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert np.array_equal(outs[0][1], outs[1][1])
+    return fin, outs[1]
+
+
+def test_device_walk_equals_host_walk_on_every_fixture(dctx):
+    """Every fixture, valid or corrupt, multi-frame and skippable ones included (as single entries they are errors for
+    both walks), plus entries that point outside the source buffer."""
+    entries = [e for e in FRAMES if "dict" not in e and e["capacity"] <= (1 << 20)]
+    frames = [read_frame(e) for e in entries]
+    caps = [e["capacity"] for e in entries]
+    total = sum(len(f) for f in frames)
+    extra = [(total + 5, 10, 0, 100), (0, total + 1, 0, 100), (total, 0, 0, 0), (3, 4, 0, 16)]
+    fin, (st, out) = _both_walks(dctx, frames, caps, extra_in=extra)
+    for i, e in enumerate(entries):
+        if e["name"].startswith(("concat", "skippable", "rec_nodict")) or e["csize"] == 0:
+            continue
+        want, werr = oracle.decompress(read_frame(e), e["capacity"])
+        assert int(st[i]["errorCode"]) == werr, e["name"]
+        if not werr:
+            o = int(fin[i]["dstOff"])
+            assert out[o:o + len(want)].tobytes() == want, e["name"]
+    assert [int(x) for x in st["errorCode"][len(entries):]] == [72, 72, 72, 72]
+
+
+def test_device_walk_with_dictionary(dctx):
+    d = read_dict("dict16k")
+    dd = api.DDict(dctx, d)
+    entries = [e for e in FRAMES if e.get("dict") == "dict16k"] + [e for e in FRAMES if e["name"] in ("text4096_l3_c1", "text128k_l3_c0")]
+    fin, (st, out) = _both_walks(dctx, [read_frame(e) for e in entries], [e["capacity"] for e in entries], ddict=dd)
+    for i, e in enumerate(entries):
+        want, werr = oracle.decompress(read_frame(e), e["capacity"], d)
+        assert int(st[i]["errorCode"]) == werr, e["name"]
+        o = int(fin[i]["dstOff"])
+        assert out[o:o + len(want)].tobytes() == want
+    dd.close()
+
+
+def test_device_walk_on_damaged_headers(dctx):
+    """Frames with bytes overwritten in their first 40 bytes (frame header, first block header, section headers),
+    truncated frames and pure noise: whatever the host walk makes of them, the device walk makes the same."""
+    rng = np.random.default_rng(77)
+    base = [read_frame(e) for e in FRAMES if e["name"] in ("text4096_l3_c1", "text128k_l3_c0", "bin128k_l19_c1", "text1m_l1", "rle300k", "text255_l3_c1")]
+    frames = []
+    for fr in base:
+        for _ in range(60):
+            a = bytearray(fr)
+            for _ in range(int(rng.integers(1, 4))):
+                a[int(rng.integers(0, min(40, len(a))))] = int(rng.integers(0, 256))
+            frames.append(bytes(a))
+        for cut in (1, 4, 5, 8, 9, 12, 20, len(fr) // 2, len(fr) - 1, len(fr) - 4):
+            frames.append(fr[:cut])
+    frames += [rng.integers(0, 256, size=int(n), dtype=np.uint8).tobytes() for n in rng.integers(1, 300, size=40)]
+    frames += [b"\x28\xb5\x2f\xfd" + rng.integers(0, 256, size=int(n), dtype=np.uint8).tobytes() for n in rng.integers(1, 300, size=60)]
+    _both_walks(dctx, frames, [1 << 20] * len(frames))
+
+
+def test_device_walk_empty_batch(dctx):
+    b = api.Batch(dctx, None, np.zeros(0, dtype=api.FRAME_IN_DTYPE), dev_src_ptr=0, dev_src_bytes=0)
+    assert b.n_blocks == 0
+    b.decode(0, 0, 0)
+    assert len(b.status()) == 0
+    b.close()

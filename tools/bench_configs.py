@@ -27,6 +27,18 @@ def run(name, frames, capacities, plain, dictionary=None, steps=5):
     d_src = torch.from_numpy(src).cuda()
     d_dst = torch.zeros(dst_bytes, dtype=torch.uint8, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
+    batch.close()
+    t0 = time.perf_counter()
+    batch = api.Batch(dctx, src, fin, ddict)      # steady state: the context hands the big buffers over
+    t_host = time.perf_counter() - t0
+    t_dev = 0.0
+    for _ in range(2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        bdev = api.Batch(dctx, None, fin, ddict, dev_src_ptr=d_src.data_ptr(), dev_src_bytes=src.nbytes)
+        t_dev = time.perf_counter() - t0
+        assert bdev.descriptor_digest == batch.descriptor_digest
+        bdev.close()
     for _ in range(2):
         batch.decode(d_src.data_ptr(), d_dst.data_ptr(), stream)
     batch.set_profiling(True)
@@ -51,7 +63,7 @@ def run(name, frames, capacities, plain, dictionary=None, steps=5):
     stage /= steps
     print(f"{name}: {n} frames, {d / 1e6:.1f} MB out, {int(fin['srcSize'].sum()) / 1e6:.1f} MB in: {d / dt / 1e9:.2f} GB/s "
           f"({dt * 1e3:.3f} ms/step; " + " ".join(f"{api.STAGE_NAMES[i]} {stage[i]:.3f}" for i in range(api.NUM_STAGES)) +
-          f"; descriptors {t_first * 1e3:.1f} ms)", flush=True)
+          f"; descriptors: host walk {t_host * 1e3:.2f} ms (first {t_first * 1e3:.1f}), device walk {t_dev * 1e3:.2f} ms)", flush=True)
 
 
 def main():

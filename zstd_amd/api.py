@@ -61,7 +61,8 @@ EXPORTS = (
     "zstdgpu_getFrameContentSize", "zstdgpu_findFrameCompressedSize", "zstdgpu_getDictID_fromDict", "zstdgpu_getDictID_fromFrame",
     "zstdgpu_createDDict", "zstdgpu_freeDDict",
     "zstdgpu_decompress", "zstdgpu_decompressDCtx", "zstdgpu_decompress_usingDict", "zstdgpu_decompress_usingDDict",
-    "zstdgpu_buildDescriptors", "zstdgpu_batch_create", "zstdgpu_batch_create_from_frames", "zstdgpu_batch_destroy",
+    "zstdgpu_buildDescriptors", "zstdgpu_batch_create", "zstdgpu_batch_create_from_frames", "zstdgpu_batch_create_on_device",
+    "zstdgpu_batch_descriptorDigest", "zstdgpu_batch_destroy",
     "zstdgpu_batch_decode", "zstdgpu_batch_status", "zstdgpu_batch_nFrames", "zstdgpu_batch_nBlocks", "zstdgpu_batch_srcBytes",
     "zstdgpu_batch_scratchBytes", "zstdgpu_batch_set_profiling", "zstdgpu_batch_stage_ms", "zstdgpu_stage_kernel_name",
     "zstdgpu_xxh64Batch", "zstdgpu_batch_blockInfo", "zstdgpu_batch_copyLiterals", "zstdgpu_batch_copySequences",
@@ -103,6 +104,8 @@ def lib():
     proto("zstdgpu_buildDescriptors", sz, vp, sz, vp, u32, vp, vp, sz)
     proto("zstdgpu_batch_create", vp, vp, vp, sz, vp, u32, vp, u32, vp)
     proto("zstdgpu_batch_create_from_frames", vp, vp, vp, sz, vp, u32, vp)
+    proto("zstdgpu_batch_create_on_device", vp, vp, vp, sz, vp, u32, vp)
+    proto("zstdgpu_batch_descriptorDigest", ctypes.c_uint64, vp)
     proto("zstdgpu_batch_destroy", None, vp)
     proto("zstdgpu_batch_decode", sz, vp, vp, vp, vp)
     proto("zstdgpu_batch_status", sz, vp, vp)
@@ -231,13 +234,21 @@ class Batch:
     """A prepared batch of independent frames: descriptors and scratch live on the GPU, `decode`
     launches the stage chain on device buffers and allocates nothing."""
 
-    def __init__(self, dctx: DCtx, host_src: np.ndarray, frames_in: np.ndarray, ddict: DDict = None, via_descriptors: bool = False):
+    def __init__(self, dctx: DCtx, host_src: np.ndarray, frames_in: np.ndarray, ddict: DDict = None, via_descriptors: bool = False,
+                 dev_src_ptr: int = 0, dev_src_bytes: int = 0):
+        """host_src: the concatenated frames in host memory (walked on the host), or None with dev_src_ptr / dev_src_bytes:
+        the same bytes in device memory, walked by device kernels."""
         L = lib()
         self.dctx, self.ddict = dctx, ddict
         self.n = len(frames_in)
-        host_src = np.ascontiguousarray(host_src, dtype=np.uint8)
         fin = np.ascontiguousarray(frames_in, dtype=FRAME_IN_DTYPE)
         dd = ddict.h if ddict else None
+        if host_src is None:
+            self.h = L.zstdgpu_batch_create_on_device(dctx.h, dev_src_ptr, dev_src_bytes, fin.ctypes.data, self.n, dd)
+            if not self.h:
+                raise ZstdError(64)
+            return
+        host_src = np.ascontiguousarray(host_src, dtype=np.uint8)
         if via_descriptors:
             fds, bds, nb = build_descriptors(host_src, fin)
             self.h = L.zstdgpu_batch_create(dctx.h, host_src.ctypes.data, host_src.nbytes, fds, self.n, bds, nb, dd)
@@ -245,6 +256,10 @@ class Batch:
             self.h = L.zstdgpu_batch_create_from_frames(dctx.h, host_src.ctypes.data, host_src.nbytes, fin.ctypes.data, self.n, dd)
         if not self.h:
             raise ZstdError(64)
+
+    @property
+    def descriptor_digest(self):
+        return lib().zstdgpu_batch_descriptorDigest(self.h)
 
     @property
     def n_blocks(self):

@@ -174,6 +174,9 @@ struct zstdgpu_batch {
     std::vector<DevBlock> hBlocks;
     std::vector<DevFrame> hFrames;
     std::vector<uint32_t> hLitJobs, hSeqJobs;
+    // counts of the arrays above; a batch built on the device fills the host copies only when a query needs them
+    uint32_t nFrames = 0, nBlocks = 0, nLitJobs = 0, nSeqJobs = 0;
+    bool mirrored = true;
     DevBlock* dBlocks = nullptr; DevBlockState* dState = nullptr; DevFrame* dFrames = nullptr; DevFrameStatus* dStatus = nullptr;
     uint8_t* dLitBuf = nullptr; uint8_t* dLitTmp = nullptr; uint4* dPackTab = nullptr; uint32_t* dSeqBuf = nullptr; uint32_t *dLitJobs = nullptr, *dSeqJobs = nullptr;
     size_t litBufBytes = 0, litTmpBytes = 0, seqBufBytes = 0;      // real sizes of the two big buffers (they return to the context's spare list)
@@ -517,6 +520,7 @@ extern "C" zstdgpu_batch* zstdgpu_batch_create(zstdgpu_ctx* ctx, const void* hos
         }
     }
     B->litBytes = litOff + 64; B->nSeqTotal = seqOff;
+    B->nFrames = nFrames; B->nBlocks = nBlocks; B->nLitJobs = (uint32_t)B->hLitJobs.size(); B->nSeqJobs = (uint32_t)B->hSeqJobs.size();
     bool ok = dalloc(B->dBlocks, nBlocks, B->scratchBytes) && dalloc(B->dState, nBlocks, B->scratchBytes) &&
               dalloc(B->dFrames, nFrames, B->scratchBytes) && dalloc(B->dStatus, nFrames, B->scratchBytes) &&
               balloc(ctx, B->dLitBuf, B->litBytes, B->litBufBytes, B->scratchBytes) && balloc(ctx, B->dLitTmp, tmpOff + 64, B->litTmpBytes, B->scratchBytes) && balloc(ctx, B->dSeqBuf, seqOff * 4 + 4, B->seqBufBytes, B->scratchBytes) &&
@@ -542,6 +546,84 @@ extern "C" zstdgpu_batch* zstdgpu_batch_create_from_frames(zstdgpu_ctx* ctx, con
     return zstdgpu_batch_create(ctx, hostSrc, srcBytes, frames.data(), nFrames, blocks.data(), (uint32_t)n2, ddict);
 }
 
+// The same batch, built without a host copy of the source: the frame / block / section headers are walked by
+// device kernels over the source in device memory (descriptors.hip); the host only sizes the buffers from the
+// totals they report and keeps a mirror of the small descriptor arrays for the query entry points.
+extern "C" zstdgpu_batch* zstdgpu_batch_create_on_device(zstdgpu_ctx* ctx, const void* devSrc, size_t srcBytes,
+                                                         const zstdgpu_frame_in* in, uint32_t nFrames, const zstdgpu_ddict* ddict)
+{
+    static_assert(sizeof(zstdgpu_frame_in) == sizeof(FrameIn), "frame entry layout");
+    if (!ctx || !set_device(ctx) || (nFrames && (!in || !devSrc))) return nullptr;
+    zstdgpu_batch* B = new (std::nothrow) zstdgpu_batch;
+    if (!B) return nullptr;
+    B->ctx = ctx; B->ddict = ddict;
+    uint32_t const batchDictID = ddict ? ddict->dictID : 0;
+    FrameIn* dIn = nullptr; uint32_t* dSlots = nullptr; uint64_t* dTotals = nullptr; uint8_t* dFlags = nullptr;
+    uint64_t tmpAcct = 0;
+    uint64_t totals[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t nBlocks = 0;
+    auto cleanup = [&]() { hipFree(dIn); hipFree(dSlots); hipFree(dTotals); hipFree(dFlags); };
+    bool ok = dalloc(B->dFrames, nFrames, B->scratchBytes) && dalloc(B->dStatus, nFrames, B->scratchBytes) &&
+              dalloc(dIn, nFrames, tmpAcct) && dalloc(dSlots, nFrames, tmpAcct) && dalloc(dTotals, 8, tmpAcct);
+    ok = ok && (nFrames == 0 || hipMemcpy(dIn, in, (size_t)nFrames * sizeof(FrameIn), hipMemcpyHostToDevice) == hipSuccess);
+    if (ok) {
+        launch_scan_frames((const uint8_t*)devSrc, srcBytes, dIn, nFrames, batchDictID, ddict ? 1u : 0u, B->dFrames, dSlots, dTotals, nullptr);
+        ok = hipMemcpy(totals, dTotals, sizeof(totals), hipMemcpyDeviceToHost) == hipSuccess && totals[0] <= 0x7FFFFFFFull;
+        nBlocks = (uint32_t)totals[0];
+    }
+    ok = ok && dalloc(B->dBlocks, nBlocks, B->scratchBytes) && dalloc(B->dState, nBlocks, B->scratchBytes) && dalloc(dFlags, nBlocks, tmpAcct) &&
+         dalloc(B->dLitJobs, nBlocks, B->scratchBytes) && dalloc(B->dSeqJobs, nBlocks, B->scratchBytes);
+    ok = ok && hipMemset(B->dBlocks, 0, (size_t)(nBlocks ? nBlocks : 1) * sizeof(DevBlock)) == hipSuccess && hipMemset(dFlags, 0, nBlocks ? nBlocks : 1) == hipSuccess;
+    if (ok) {
+        launch_fill_blocks((const uint8_t*)devSrc, srcBytes, dIn, nFrames, batchDictID, ddict ? 1u : 0u, (ddict && ddict->hasEntropy) ? 1u : 0u,
+                           B->dFrames, B->dBlocks, dFlags, nBlocks, B->dLitJobs, B->dSeqJobs, dTotals, nullptr);
+        ok = hipMemcpy(totals, dTotals, sizeof(totals), hipMemcpyDeviceToHost) == hipSuccess;
+    }
+    if (ok) {
+        uint64_t const litOff = totals[1], tmpOff = totals[2], seqOff = totals[3];
+        size_t const nLit = (size_t)totals[4], nSeq = (size_t)totals[5];
+        B->litBytes = litOff + 64; B->nSeqTotal = seqOff;
+        ok = balloc(ctx, B->dLitBuf, B->litBytes, B->litBufBytes, B->scratchBytes) && balloc(ctx, B->dLitTmp, tmpOff + 64, B->litTmpBytes, B->scratchBytes) &&
+             balloc(ctx, B->dSeqBuf, seqOff * 4 + 4, B->seqBufBytes, B->scratchBytes) && dalloc(B->dPackTab, nLit * 17 + 1, B->scratchBytes);
+        B->nFrames = nFrames; B->nBlocks = nBlocks; B->nLitJobs = (uint32_t)nLit; B->nSeqJobs = (uint32_t)nSeq;
+        B->srcBytes = totals[6];
+        B->mirrored = false;
+    }
+    ok = ok && hipStreamCreateWithFlags(&B->side, hipStreamNonBlocking) == hipSuccess &&
+         hipEventCreateWithFlags(&B->evFork, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&B->evJoin, hipEventDisableTiming) == hipSuccess;
+    cleanup();
+    if (!ok) { free_batch_device(B); delete B; return nullptr; }
+    return B;
+}
+
+// Host copies of the descriptor arrays of a batch that was built on the device.
+static bool mirror(zstdgpu_batch* B)
+{
+    if (B->mirrored) return true;
+    if (!set_device(B->ctx)) return false;
+    B->hBlocks.resize(B->nBlocks); B->hFrames.resize(B->nFrames); B->hLitJobs.resize(B->nLitJobs); B->hSeqJobs.resize(B->nSeqJobs);
+    auto down = [&](void* h, const void* d, size_t n) { return n == 0 || hipMemcpy(h, d, n, hipMemcpyDeviceToHost) == hipSuccess; };
+    bool const ok = down(B->hBlocks.data(), B->dBlocks, (size_t)B->nBlocks * sizeof(DevBlock)) && down(B->hFrames.data(), B->dFrames, (size_t)B->nFrames * sizeof(DevFrame)) &&
+                    down(B->hLitJobs.data(), B->dLitJobs, (size_t)B->nLitJobs * 4) && down(B->hSeqJobs.data(), B->dSeqJobs, (size_t)B->nSeqJobs * 4);
+    B->mirrored = ok;
+    return ok;
+}
+
+// FNV-1a over the descriptor arrays of a batch (blocks, frames, job lists): two batches built from the same input by
+// the host walk and by the device walk must agree.
+extern "C" uint64_t zstdgpu_batch_descriptorDigest(zstdgpu_batch* b)
+{
+    if (!b || !mirror(b)) return 0;
+    uint64_t h = 0xCBF29CE484222325ull;
+    auto mix = [&](const void* p, size_t n) { const uint8_t* q = (const uint8_t*)p; for (size_t i = 0; i < n; i++) { h ^= q[i]; h *= 0x100000001B3ull; } };
+    if (!b) return 0;
+    mix(b->hBlocks.data(), b->hBlocks.size() * sizeof(DevBlock));
+    mix(b->hFrames.data(), b->hFrames.size() * sizeof(DevFrame));
+    mix(b->hLitJobs.data(), b->hLitJobs.size() * 4);
+    mix(b->hSeqJobs.data(), b->hSeqJobs.size() * 4);
+    return h;
+}
+
 extern "C" void zstdgpu_batch_destroy(zstdgpu_batch* b)
 {
     if (!b) return;
@@ -558,8 +640,8 @@ extern "C" size_t zstdgpu_batch_decode(zstdgpu_batch* B, const void* devSrc, voi
     p.src = (const uint8_t*)devSrc; p.dst = (uint8_t*)devDst;
     p.blocks = B->dBlocks; p.state = B->dState; p.frames = B->dFrames; p.status = B->dStatus;
     p.litBuf = B->dLitBuf; p.litTmp = B->dLitTmp; p.packTab = B->dPackTab; p.seqBuf = B->dSeqBuf; p.litJobs = B->dLitJobs; p.seqJobs = B->dSeqJobs;
-    p.nLitJobs = (uint32_t)B->hLitJobs.size(); p.nSeqJobs = (uint32_t)B->hSeqJobs.size();
-    p.nFrames = (uint32_t)B->hFrames.size(); p.nBlocks = (uint32_t)B->hBlocks.size();
+    p.nLitJobs = B->nLitJobs; p.nSeqJobs = B->nSeqJobs;
+    p.nFrames = B->nFrames; p.nBlocks = B->nBlocks;
     if (B->ddict) {
         p.dict = B->ddict->dDict;
         p.dictContent = B->ddict->dBytes + B->ddict->entropySize;
@@ -623,14 +705,14 @@ extern "C" size_t zstdgpu_batch_status(zstdgpu_batch* B, zstdgpu_frame_status* s
     if (!B || !set_device(B->ctx)) return mkerr(E_generic);
     if (hipStreamSynchronize(B->lastStream) != hipSuccess) return mkerr(E_generic);
     static_assert(sizeof(zstdgpu_frame_status) == sizeof(DevFrameStatus), "status layout");
-    if (status && !B->hFrames.empty() &&
-        hipMemcpy(status, B->dStatus, B->hFrames.size() * sizeof(DevFrameStatus), hipMemcpyDeviceToHost) != hipSuccess)
+    if (status && B->nFrames &&
+        hipMemcpy(status, B->dStatus, (size_t)B->nFrames * sizeof(DevFrameStatus), hipMemcpyDeviceToHost) != hipSuccess)
         return mkerr(E_generic);
     return 0;
 }
 
-extern "C" uint32_t zstdgpu_batch_nFrames(const zstdgpu_batch* b) { return (uint32_t)b->hFrames.size(); }
-extern "C" uint32_t zstdgpu_batch_nBlocks(const zstdgpu_batch* b) { return (uint32_t)b->hBlocks.size(); }
+extern "C" uint32_t zstdgpu_batch_nFrames(const zstdgpu_batch* b) { return b->nFrames; }
+extern "C" uint32_t zstdgpu_batch_nBlocks(const zstdgpu_batch* b) { return b->nBlocks; }
 extern "C" uint64_t zstdgpu_batch_srcBytes(const zstdgpu_batch* b) { return b->srcBytes; }
 extern "C" uint64_t zstdgpu_batch_scratchBytes(const zstdgpu_batch* b) { return b->scratchBytes; }
 
@@ -679,7 +761,7 @@ extern "C" size_t zstdgpu_xxh64Batch(zstdgpu_ctx* ctx, const void* devBase, cons
 
 extern "C" size_t zstdgpu_batch_blockInfo(zstdgpu_batch* B, uint32_t bi, uint32_t* litSize, uint32_t* nbSeq, uint64_t* regenSize, uint32_t* errorCode)
 {
-    if (!B || bi >= B->hBlocks.size() || !set_device(B->ctx)) return mkerr(E_generic);
+    if (!B || bi >= B->nBlocks || !set_device(B->ctx) || !mirror(B)) return mkerr(E_generic);
     if (hipStreamSynchronize(B->lastStream) != hipSuccess) return mkerr(E_generic);
     DevBlockState st;
     if (hipMemcpy(&st, B->dState + bi, sizeof(st), hipMemcpyDeviceToHost) != hipSuccess) return mkerr(E_generic);
@@ -693,7 +775,7 @@ extern "C" size_t zstdgpu_batch_blockInfo(zstdgpu_batch* B, uint32_t bi, uint32_
 
 extern "C" size_t zstdgpu_batch_copyLiterals(zstdgpu_batch* B, const void* devSrc, uint32_t bi, void* out, size_t cap)
 {
-    if (!B || bi >= B->hBlocks.size() || !set_device(B->ctx)) return mkerr(E_generic);
+    if (!B || bi >= B->nBlocks || !set_device(B->ctx) || !mirror(B)) return mkerr(E_generic);
     if (hipStreamSynchronize(B->lastStream) != hipSuccess) return mkerr(E_generic);
     const DevBlock& d = B->hBlocks[bi];
     if (d.blockType != BT_COMPRESSED || d.hostLitErr) return mkerr(E_generic);
@@ -713,7 +795,7 @@ extern "C" size_t zstdgpu_batch_copyLiterals(zstdgpu_batch* B, const void* devSr
 
 extern "C" size_t zstdgpu_batch_copySequences(zstdgpu_batch* B, uint32_t bi, uint32_t* triples, size_t tripleCapacity)
 {
-    if (!B || bi >= B->hBlocks.size() || !set_device(B->ctx)) return mkerr(E_generic);
+    if (!B || bi >= B->nBlocks || !set_device(B->ctx) || !mirror(B)) return mkerr(E_generic);
     if (hipStreamSynchronize(B->lastStream) != hipSuccess) return mkerr(E_generic);
     const DevBlock& d = B->hBlocks[bi];
     if (d.blockType != BT_COMPRESSED || d.hostLitErr || d.hostSeqErr) return mkerr(E_generic);

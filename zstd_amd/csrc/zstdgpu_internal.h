@@ -110,6 +110,18 @@ struct BatchParams {
 #endif
 };
 
+// One source frame of a batch (same layout as zstdgpu_frame_in).
+struct FrameIn { uint64_t srcOff, srcSize, dstOff, dstCapacity; };
+
+// descriptor builder on the device (descriptors.hip).  totals: [0] block slots, [1] literal buffer bytes,
+// [2] split-decode scratch bytes, [3] sequence records, [4] literal jobs, [5] sequence jobs, [6] source bytes of the
+// frames without a header error (8 entries)
+void launch_scan_frames(const uint8_t* src, uint64_t srcBytes, const FrameIn* in, uint32_t nFrames, uint32_t batchDictID, uint32_t haveDict,
+                        DevFrame* frames, uint32_t* slots, uint64_t* totals, void* stream);
+void launch_fill_blocks(const uint8_t* src, uint64_t srcBytes, const FrameIn* in, uint32_t nFrames, uint32_t batchDictID, uint32_t haveDict,
+                        uint32_t dictEntropy, const DevFrame* frames, DevBlock* blocks, uint8_t* flags, uint32_t nBlocks,
+                        uint32_t* litJobs, uint32_t* seqJobs, uint64_t* totals, void* stream);
+
 // kernel launchers (kernels.hip)
 void launch_literals(const BatchParams& p, void* stream);
 void launch_pack_literals(const BatchParams& p, void* stream);
