@@ -301,3 +301,18 @@ def test_device_walk_empty_batch(dctx):
     b.decode(0, 0, 0)
     assert len(b.status()) == 0
     b.close()
+
+
+def test_device_walk_many_blocks(dctx):
+    """More blocks than one scan tile holds (1024), of mixed kinds, so that offsets and job lists carry across tiles."""
+    names = ("text4096_l3_c1", "text255_l3_c1", "rle300k", "text1m_l1", "empty_c1", "bin128k_l19_c1", "cor_b_flip63")
+    base = [next(e for e in FRAMES if e["name"] == n) for n in names]
+    entries = [base[i % len(base)] for i in range(2600)]
+    fin, (st, out) = _both_walks(dctx, [read_frame(e) for e in entries], [e["capacity"] for e in entries])
+    want = {e["name"]: oracle.decompress(read_frame(e), e["capacity"]) for e in base}
+    for i in (0, 1, 2, 3, 4, 5, 6, 1023, 1024, 1025, 2047, 2048, 2599):
+        w, werr = want[entries[i]["name"]]
+        assert int(st[i]["errorCode"]) == werr
+        if not werr:
+            o = int(fin[i]["dstOff"])
+            assert out[o:o + len(w)].tobytes() == w

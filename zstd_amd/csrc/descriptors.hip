@@ -165,27 +165,47 @@ __global__ __launch_bounds__(64) void k_scan_frames(const uint8_t* src, uint64_t
     slots[fi] = n;
 }
 
-// ---- exclusive prefix sum of the slots into frames[].firstBlock; total -> *total.  One workgroup.
+// Exclusive prefix sum of v over the workgroup's kScanThreads threads (two packed 32-bit counters may ride in one
+// 64-bit value as long as neither half overflows inside a tile); `total` = sum over the workgroup.
 constexpr int kScanThreads = 1024;
+DEVI uint64_t wg_excl_scan(uint64_t v, uint64_t* waveTot, uint64_t& total)
+{
+    uint32_t const t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    uint64_t incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint64_t const o = ((uint64_t)(uint32_t)__shfl_up((int)(uint32_t)(incl >> 32), d) << 32) | (uint32_t)__shfl_up((int)(uint32_t)incl, d);
+        if (lane >= (uint32_t)d) incl += o;
+    }
+    __syncthreads();                 // the previous use of waveTot is over
+    if (lane == 63) waveTot[wave] = incl;
+    __syncthreads();
+    uint64_t before = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < kScanThreads / 64; w++) { uint64_t const x = waveTot[w]; all += x; if ((uint32_t)w < wave) before += x; }
+    total = all;
+    return before + incl - v;
+}
+
+// ---- exclusive prefix sum of the slots into frames[].firstBlock; total -> totals[0].  One workgroup, tiles of
+// kScanThreads frames.
 __global__ __launch_bounds__(kScanThreads) void k_first_blocks(const uint32_t* slots, const FrameIn* in, uint32_t nFrames, DevFrame* frames, uint64_t* totals)
 {
-    __shared__ uint64_t part[kScanThreads];
+    __shared__ uint64_t waveTot[kScanThreads / 64];
     uint32_t const t = threadIdx.x;
-    uint32_t const chunk = (nFrames + kScanThreads - 1) / kScanThreads;
-    uint32_t const lo = t * chunk < nFrames ? t * chunk : nFrames, hi = lo + chunk < nFrames ? lo + chunk : nFrames;
-    uint64_t sum = 0, bytes = 0;
-    for (uint32_t i = lo; i < hi; i++) { sum += slots[i]; if (!frames[i].hostError) bytes += in[i].srcSize; }
-    part[t] = sum;
-    if (bytes) atomicAdd((unsigned long long*)&totals[6], (unsigned long long)bytes);      // source bytes of the frames that will be decoded
-    __syncthreads();
-    if (t == 0) {
-        uint64_t run = 0;
-        for (int i = 0; i < kScanThreads; i++) { uint64_t const v = part[i]; part[i] = run; run += v; }
-        totals[0] = run;
+    uint64_t carry = 0, bytes = 0;
+    for (uint32_t base = 0; base < nFrames; base += kScanThreads) {
+        uint32_t const i = base + t;
+        bool const in_ = i < nFrames;
+        uint64_t const v = in_ ? slots[i] : 0;
+        if (in_ && !frames[i].hostError) bytes += in[i].srcSize;
+        uint64_t tileTotal;
+        uint64_t const ex = wg_excl_scan(v, waveTot, tileTotal);
+        if (in_) frames[i].firstBlock = (uint32_t)(carry + ex);
+        carry += tileTotal;
     }
-    __syncthreads();
-    uint64_t run = part[t];
-    for (uint32_t i = lo; i < hi; i++) { frames[i].firstBlock = (uint32_t)run; run += slots[i]; }
+    if (bytes) atomicAdd((unsigned long long*)&totals[6], (unsigned long long)bytes);      // source bytes of the frames that will be decoded
+    if (t == 0) totals[0] = carry;
 }
 
 // ---- launch 2: the block descriptors of every frame.  The scratch offsets hold the block's needs for now
@@ -244,44 +264,38 @@ __global__ __launch_bounds__(64) void k_fill_blocks(const uint8_t* src, uint64_t
     });
 }
 
-// ---- launch 3: every block's place in the scratch buffers and the job lists, in block order.  One workgroup.
+// ---- launch 3: every block's place in the scratch buffers and the job lists, in block order.  One workgroup, tiles
+// of kScanThreads blocks; inside a tile the literal-buffer and scratch bytes share one 64-bit scan (each < 2^32 per
+// tile), the sequence records and the two job counts another.
 // totals: [1] literal buffer bytes, [2] split-decode scratch bytes, [3] sequence records, [4] literal jobs, [5] sequence jobs.
 __global__ __launch_bounds__(kScanThreads) void k_block_offsets(DevBlock* blocks, const uint8_t* flags, uint32_t nBlocks,
                                                                 uint32_t* litJobs, uint32_t* seqJobs, uint64_t* totals)
 {
-    __shared__ uint64_t part[5][kScanThreads];
+    __shared__ uint64_t waveTot[kScanThreads / 64];
     uint32_t const t = threadIdx.x;
-    uint32_t const chunk = (nBlocks + kScanThreads - 1) / kScanThreads;
-    uint32_t const lo = t * chunk < nBlocks ? t * chunk : nBlocks, hi = lo + chunk < nBlocks ? lo + chunk : nBlocks;
-    uint64_t s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0;
-    for (uint32_t b = lo; b < hi; b++) {
-        uint32_t const fl = flags[b];
-        if (fl & 1) { s0 += blocks[b].litBufOff; s1 += blocks[b].litTmpOff; s3++; }
-        if (fl & 2) { s2 += blocks[b].seqBufOff; s4++; }
-    }
-    part[0][t] = s0; part[1][t] = s1; part[2][t] = s2; part[3][t] = s3; part[4][t] = s4;
-    __syncthreads();
-    if (t < 5) {
-        uint64_t run = 0;
-        for (int i = 0; i < kScanThreads; i++) { uint64_t const v = part[t][i]; part[t][i] = run; run += v; }
-        totals[1 + t] = run;
-    }
-    __syncthreads();
-    s0 = part[0][t]; s1 = part[1][t]; s2 = part[2][t]; s3 = part[3][t]; s4 = part[4][t];
-    for (uint32_t b = lo; b < hi; b++) {
-        uint32_t const fl = flags[b];
+    uint64_t cLit = 0, cTmp = 0, cSeq = 0, cLitJobs = 0, cSeqJobs = 0;
+    for (uint32_t base = 0; base < nBlocks; base += kScanThreads) {
+        uint32_t const b = base + t;
+        uint32_t const fl = b < nBlocks ? flags[b] : 0;
+        uint64_t lit = 0, tmp = 0, seq = 0;
+        if (fl & 1) { lit = blocks[b].litBufOff; tmp = blocks[b].litTmpOff; }
+        if (fl & 2) seq = blocks[b].seqBufOff;
+        uint64_t totA, totB;
+        uint64_t const exA = wg_excl_scan(lit | (tmp << 32), waveTot, totA);
+        uint64_t const exB = wg_excl_scan(seq | ((uint64_t)(fl & 1) << 32) | ((uint64_t)((fl >> 1) & 1) << 48), waveTot, totB);
         if (fl & 1) {
-            uint64_t const a = blocks[b].litBufOff, w = blocks[b].litTmpOff;
-            blocks[b].litBufOff = s0; s0 += a;
-            blocks[b].litTmpOff = w ? s1 : 0; s1 += w;
-            litJobs[s3++] = b;
+            blocks[b].litBufOff = cLit + (uint32_t)exA;
+            blocks[b].litTmpOff = tmp ? cTmp + (exA >> 32) : 0;
+            litJobs[cLitJobs + ((exB >> 32) & 0xFFFF)] = b;
         }
         if (fl & 2) {
-            uint64_t const a = blocks[b].seqBufOff;
-            blocks[b].seqBufOff = s2; s2 += a;
-            seqJobs[s4++] = b;
+            blocks[b].seqBufOff = cSeq + (uint32_t)exB;
+            seqJobs[cSeqJobs + (exB >> 48)] = b;
         }
+        cLit += (uint32_t)totA; cTmp += totA >> 32;
+        cSeq += (uint32_t)totB; cLitJobs += (totB >> 32) & 0xFFFF; cSeqJobs += totB >> 48;
     }
+    if (t == 0) { totals[1] = cLit; totals[2] = cTmp; totals[3] = cSeq; totals[4] = cLitJobs; totals[5] = cSeqJobs; }
 }
 
 }  // namespace
