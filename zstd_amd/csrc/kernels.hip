@@ -144,6 +144,15 @@ DEVI uint4 ld_unit(uintptr_t addr, uintptr_t floor)
     return make_uint4(x.x, x.y, x.z, x.w);
 }
 
+// the same at any byte address
+DEVI uint4 ld_unit_any(uintptr_t addr, uintptr_t floor)
+{
+    typedef uint32_t u32x4a1 __attribute__((ext_vector_type(4), aligned(1)));
+    typedef const __attribute__((address_space(1))) u32x4a1* gptr;
+    u32x4a1 const x = *(gptr)(addr >= floor ? addr : floor);
+    return make_uint4(x.x, x.y, x.z, x.w);
+}
+
 // ---------------------------------------------------------------- FSE_readNCount (entropy_common.pas:83-256)
 constexpr uint32_t kFail = 0xFFFFFFFFu;
 
@@ -654,7 +663,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
             uint8_t* const tmpL = p.litTmp + blk.litTmpOff + (size_t)sl * laneCap;
             uint32_t* const winL = inWin + sl * kSpecWinDw;
             uint32_t* const soL = (uint32_t*)(outStage + sl * kSpecRound);
-            uintptr_t wbL = 0;
+            uintptr_t wbL = 0, pwb = 0;
+            uint4 pv[6];                    // the window requested during the previous round
+            bool havePv = false;
             bool prevActive = false;
             uint32_t rem = 0;               // the 32 bits below the cursor, of which the top 20 or more are known from the last group
 #ifdef ZG_STAMPS
@@ -666,15 +677,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
 #endif
                 bool const active = !met && !failed;
                 bool const anyActive = ((__ballot(active) >> lead) & 0xFFFFu) != 0;
-                // window of this lane: 6 aligned units ending just above its unread bits; loaded again when it runs low
-                bool const low = active && (r == 0 || (int)(8 * (int64_t)((uintptr_t)myStart - wbL)) + cur < (int)(12 * kSpecRound + 96));
+                // Window of this lane: 6 aligned units ending just above its unread bits.  Every round requests the window
+                // for the next one (placed at the cursor it starts from), so the load is over when it is needed; only when a
+                // round eats so much that this window cannot feed the next round is one loaded on the spot.
+                uintptr_t const wbCand = havePv ? pwb : wbL;
+                bool const low = active && (r == 0 || (int)(8 * (int64_t)((uintptr_t)myStart - wbCand)) + cur < (int)(tableLog * kSpecRound + 96));
                 bool const stage = anyActive && ((__ballot(low) >> lead) & 0xFFFFu) != 0;
                 uint4 v[6];
-                if (stage) {
+                uintptr_t wbS = 0;
+                // (a window ends at the byte that holds the cursor: byte-aligned loads lose no more than 7 bits to alignment; only
+                // a window that would reach below the source buffer keeps to 16-byte units, which the clamp in the load needs)
+                auto window_base = [&]() -> uintptr_t {
                     uintptr_t const top = (uintptr_t)myStart + (uintptr_t)((cur > 0 ? cur + 7 : 0) >> 3);
-                    wbL = ((top + 15) & ~(uintptr_t)15) - 4 * kSpecWinDw;
+                    uintptr_t const exact = top - 4 * kSpecWinDw;
+                    return exact >= floorAddr ? exact : ((top + 15) & ~(uintptr_t)15) - 4 * kSpecWinDw;
+                };
+                if (stage) {
+                    wbS = window_base();
 #pragma unroll
-                    for (int q = 0; q < 6; q++) v[q] = ld_unit(wbL + 16 * q, floorAddr);
+                    for (int q = 0; q < 6; q++) v[q] = ld_unit_any(wbS + 16 * q, floorAddr);
                 }
                 // the previous round's bytes go to the lane's scratch region
                 if (prevActive) {
@@ -688,10 +709,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
 #endif
                 lds_sync();
                 if (stage) {
+                    wbL = wbS;
 #pragma unroll
                     for (int q = 0; q < 6; q++) *(uint4*)(winL + 4 * q) = v[q];
+                } else if (havePv) {
+                    wbL = pwb;
+#pragma unroll
+                    for (int q = 0; q < 6; q++) *(uint4*)(winL + 4 * q) = pv[q];
                 }
                 lds_sync();
+                {   // the window the next round will start from
+                    pwb = window_base();
+#pragma unroll
+                    for (int q = 0; q < 6; q++) pv[q] = ld_unit_any(pwb + 16 * q, floorAddr);
+                    havePv = true;
+                }
 #ifdef ZG_STAMPS
                 uint64_t const zc = __builtin_readcyclecounter();
                 zA += zb - za; zB += zc - zb; zR += 1; zS += stage ? 1 : 0;
