@@ -153,6 +153,25 @@ DEVI uint4 ld_unit_any(uintptr_t addr, uintptr_t floor)
     return make_uint4(x.x, x.y, x.z, x.w);
 }
 
+// n <= 256 bytes from global memory into LDS (16-byte aligned there) by a group of 16 lanes: one 16-byte load per
+// lane, all in flight together; the last, partial chunk is loaded as the 16 bytes that end with byte n - 1.
+DEVI void grp_stage_bytes(uint8_t* dst, const uint8_t* src, uint32_t n, uint32_t gl)
+{
+    typedef uint32_t u32x4a1 __attribute__((ext_vector_type(4), aligned(1)));
+    uint32_t const full = n >> 4;
+    if (gl < full) {
+        u32x4a1 const x = *(const u32x4a1*)(src + 16 * gl);
+        *(uint4*)(dst + 16 * gl) = make_uint4(x.x, x.y, x.z, x.w);
+    } else if (gl == full && (n & 15)) {
+        if (n >= 16) {
+            u32x4a1 const x = *(const u32x4a1*)(src + n - 16);
+            __builtin_memcpy(dst + n - 16, &x, 16);
+        } else {
+            for (uint32_t i = 0; i < n; i++) dst[i] = src[i];
+        }
+    }
+}
+
 // ---------------------------------------------------------------- FSE_readNCount (entropy_common.pas:83-256)
 constexpr uint32_t kFail = 0xFFFFFFFFu;
 
@@ -526,7 +545,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
         DevBlock const sb = (blk.hufSrc == (int32_t)b) ? blk : p.blocks[blk.hufSrc];
         const uint8_t* const dp = p.src + sb.srcOff + sb.litHdrSize;
         descAvail = sb.litCSize < 136 ? sb.litCSize : 136;
-        for (uint32_t i = sl; i < descAvail + 8; i += kHufLanes) hdrStage[i] = dp[(int)i - 8];
+        grp_stage_bytes(hdrStage, dp - 8, descAvail + 8, sl);
     }
     lds_sync();
     uint32_t nListed = 0;
@@ -1403,7 +1422,7 @@ __global__ __launch_bounds__(kSeqThreads) void k_sequences(BatchParams p)
             static_assert(512 + kGrpBuildScratch <= 4 * (4 * (kWinUnits + 1) + 2 * 4 * kSeqRound), "table scratch fits");
             uint32_t const hdrAvail = off < blk.cSize ? blk.cSize - off : 0;
             uint32_t const nStaged = hdrAvail < 256 ? hdrAvail : 256;
-            for (uint32_t i = gl; i < nStaged; i += 16) hdr[i] = payload[off + i];
+            grp_stage_bytes(hdr, payload + off, nStaged, gl);
             lds_sync();
             bool fail = false;
             uint32_t done = 0;          // description bytes consumed so far
