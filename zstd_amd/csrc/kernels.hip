@@ -1997,14 +1997,24 @@ DEVI uint64_t uni(uint64_t v) { return ((uint64_t)uni((uint32_t)(v >> 32)) << 32
 DEVI uint32_t lane_value(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
 
 constexpr uint32_t kOutStage = 4096;     // output bytes of one batch assembled in LDS
+constexpr uint32_t kOutHist = 6656;      // the output stage: a batch and the output of the batches before it
 constexpr uint32_t kLitStage = 1024;     // literal bytes of one batch staged in LDS
 
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_execute(BatchParams p)
 {
-    __shared__ uint32_t sStart[65], sLL[64], sOff[64], sLit[64], sSlowEnd[64];
-    __shared__ __attribute__((aligned(16))) uint8_t outStage[kOutStage];
+    // The output stage holds the batch being assembled and, before it, what the batches before it produced (as long as
+    // they were assembled here and the next one still fits): a match whose source lies in that history is copied
+    // inside LDS and costs no memory access.
+    __shared__ __attribute__((aligned(16))) uint8_t outStage[kOutHist];
     __shared__ __attribute__((aligned(16))) uint8_t litStage[kLitStage];
     __shared__ __attribute__((aligned(16))) uint8_t matStage[64 * 32];      // 32 source bytes per lane
+    // the sequence table of a batch that goes from memory to memory (it uses none of the stages)
+    uint32_t* const sStart = (uint32_t*)matStage;
+    uint32_t* const sLL = sStart + 65;
+    uint32_t* const sOff = sLL + 64;
+    uint32_t* const sLit = sOff + 64;
+    uint32_t* const sSlowEnd = sLit + 64;
+    static_assert((65 + 4 * 64) * 4 <= 64 * 32, "the sequence table fits in the match stage");
     uint32_t const lane = threadIdx.x;
     uint32_t const fi = blockIdx.x;
     DevFrame const f = p.frames[fi];
@@ -2082,11 +2092,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
         struct Plan {
             uint32_t start, ll, lstart, off, ml, gcnt, gEnd;
             int64_t absS;
-            bool have, plain, fastS;
+            bool have, plain, fastS, nearS;
             uint32_t total, lit0, sumLL, base0, litEnd, err;
+            uint32_t hp;        // where the batch starts in the output stage = bytes of history in front of it
             bool staged;
         };
-        auto make_plan = [&](uint4 const rc, uint2 const endV, uint32_t const s) -> Plan {
+        // prev: the plan of the batch before (its place in the stage decides how much history this one finds)
+        auto make_plan = [&](uint4 const rc, uint2 const endV, uint32_t const s, bool const prevStaged, uint32_t const prevEnd) -> Plan {
             Plan q;
             uint32_t const n = s < nValid ? (nValid - s < 64 ? nValid - s : 64) : 0;
             q.have = lane < n;
@@ -2123,19 +2135,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
             q.lit0 = lane_value(q.lstart, 0);
             q.sumLL = endZ - q.lit0;          // the literals of a batch are contiguous
             int64_t const fetchEnd = q.absS + (q.ml > 16 ? 32 : 16);
-            q.fastS = q.plain && (q.absS >= 0 ? fetchEnd <= (int64_t)cap : fetchEnd <= 0);
-            uint32_t const slowS = (q.have && !q.fastS) ? q.ml : 0;
+            bool const fetchable = q.plain && (q.absS >= 0 ? fetchEnd <= (int64_t)cap : fetchEnd <= 0);
+            uint32_t const slowS = (q.have && !fetchable) ? q.ml : 0;
             // of a match handled in LDS, the leading bytes whose source lies before the batch come from memory, one per lane
             int64_t const lead = -ms < (int64_t)(q.ml < q.off ? q.ml : q.off) ? -ms : (int64_t)(q.ml < q.off ? q.ml : q.off);
             q.gcnt = (slowS && lead > 0) ? (uint32_t)lead : 0u;
             q.gEnd = wave_incl_scan(q.gcnt);
             q.staged = q.total <= kOutStage && q.sumLL <= kLitStage && lane_value(q.gEnd, 63) <= 64 && !__any(q.ll > 32 || (q.plain && q.ml > 32));
+            q.hp = (q.staged && prevStaged && prevEnd + q.total <= kOutHist) ? prevEnd : 0u;
+            q.nearS = fetchable && (uint64_t)(-ms) <= q.hp;          // source inside the history: no fetch
+            q.fastS = fetchable && !q.nearS;
             return q;
         };
         Plan pl = {};
         if (nValid) {
             load_recs(0, rcN, endN);
-            pl = make_plan(rcN, endN, 0);
+            pl = make_plan(rcN, endN, 0, false, 0);
             load_recs(64, rcN, endN);
         }
         for (uint32_t s0 = 0; s0 < nValid; s0 += 64) {
@@ -2144,12 +2159,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
 #endif
             if (pl.err) { ferr = pl.err; break; }
             load_recs(s0 + 128, rcB, endB);      // ahead of the batch's own loads: the wait for those covers it
-            bool const have = pl.have, plain = pl.plain, fastS = pl.fastS, staged = pl.staged;
+            bool const have = pl.have, plain = pl.plain, fastS = pl.fastS, nearS = pl.nearS, staged = pl.staged;
+            uint32_t const hp = pl.hp;
+            uint8_t* const outB = outStage + hp;     // the batch's place in the output stage
             uint32_t const start = pl.start, ll = pl.ll, lstart = pl.lstart, off = pl.off, ml = pl.ml, gcnt = pl.gcnt, gEnd = pl.gEnd;
             uint32_t const total = pl.total, lit0 = pl.lit0, sumLL = pl.sumLL, base0 = pl.base0;
             int64_t const absS = pl.absS;
             int64_t const batchAbs = (int64_t)(bo + base0);
-            uint32_t const slowS = (have && !fastS) ? ml : 0;
+            uint32_t const slowS = (have && !fastS && !nearS) ? ml : 0;
             const uint8_t* const matSrc = absS >= 0 ? fdst + absS : dictEnd + absS;
 #ifdef ZG_STAMPS
             uint64_t const x1 = __builtin_readcyclecounter();
@@ -2191,7 +2208,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
             x2 = __builtin_readcyclecounter();
 #endif
             // ---- while those are in flight: the next batch's plan
-            Plan const plN = make_plan(rcN, endN, s0 + 64);
+            Plan const plN = make_plan(rcN, endN, s0 + 64, staged, hp + total);
             if (staged) {
                 // ---- literals and fetched match bytes into LDS, then every run into its place in the output stage
                 lds_sync();       // the previous batch's reads of the stages are done
@@ -2206,8 +2223,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
                 x3 = __builtin_readcyclecounter();
 #endif
                 lds_sync();
-                lds_copy_runs(outStage + start, litStage + (litRle ? 0u : lstart - lit0), ll, outStage + start + ll, matStage + 32 * lane, fastLen);
-                if (gdst != 0xFFFFFFFFu) outStage[gdst] = gv;
+                lds_copy_runs(outB + start, litStage + (litRle ? 0u : lstart - lit0), ll,
+                              outB + start + ll, nearS ? outB + start + ll - off : matStage + 32 * lane, nearS ? ml : fastLen);
+                if (gdst != 0xFFFFFFFFu) outB[gdst] = gv;
                 // ---- the other matches, one after the other in sequence order: everything before a match is in place
                 // when its turn comes.  Byte j repeats pattern byte j mod offset; the pattern is the `offset` bytes before
                 // the match, of which those before the batch were fetched to the head of the match itself.
@@ -2221,10 +2239,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
                         if (o < m) {
                             for (uint32_t j = g + lane; j < m; j += 64) {
                                 uint32_t const q = j % o;
-                                outStage[d0 + j] = outStage[q < g ? d0 + q : d0 - o + q];
+                                outB[d0 + j] = outB[q < g ? d0 + q : d0 - o + q];
                             }
                         } else {
-                            for (uint32_t j = g + lane; j < m; j += 64) outStage[d0 + j] = outStage[d0 - o + j];
+                            for (uint32_t j = g + lane; j < m; j += 64) outB[d0 + j] = outB[d0 - o + j];
                         }
                     }
                 }
@@ -2234,10 +2252,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
                     uint8_t* const d0 = fdst + bo + base0;
                     uint32_t const full = total >> 4, tail = total & 15;
                     for (uint32_t u = lane; u < full; u += 64) {
-                        uint4 const x = *(const uint4*)(outStage + 16 * u);
+                        uint4 x;
+                        __builtin_memcpy(&x, outB + 16 * u, 16);
                         __builtin_memcpy(d0 + 16 * u, &x, 16);
                     }
-                    if (lane < tail) d0[16 * full + lane] = outStage[16 * full + lane];
+                    if (lane < tail) d0[16 * full + lane] = outB[16 * full + lane];
                 }
 #ifdef ZG_STAMPS
                 x4 = __builtin_readcyclecounter();
