@@ -1997,7 +1997,8 @@ DEVI uint64_t uni(uint64_t v) { return ((uint64_t)uni((uint32_t)(v >> 32)) << 32
 DEVI uint32_t lane_value(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
 
 constexpr uint32_t kOutStage = 4096;     // output bytes of one batch assembled in LDS
-constexpr uint32_t kOutHist = 6656;      // the output stage: a batch and the output of the batches before it
+constexpr uint32_t kOutHist = 7168;      // the output stage: a batch and the output of the batches before it
+constexpr uint32_t kOutKeep = kOutHist - kOutStage;     // history kept when the stage is full (its tail moves to the front)
 constexpr uint32_t kLitStage = 1024;     // literal bytes of one batch staged in LDS
 
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_execute(BatchParams p)
@@ -2095,6 +2096,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
             bool have, plain, fastS, nearS;
             uint32_t total, lit0, sumLL, base0, litEnd, err;
             uint32_t hp;        // where the batch starts in the output stage = bytes of history in front of it
+            uint32_t shift;
             bool staged;
         };
         // prev: the plan of the batch before (its place in the stage decides how much history this one finds)
@@ -2142,7 +2144,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
             q.gcnt = (slowS && lead > 0) ? (uint32_t)lead : 0u;
             q.gEnd = wave_incl_scan(q.gcnt);
             q.staged = q.total <= kOutStage && q.sumLL <= kLitStage && lane_value(q.gEnd, 63) <= 64 && !__any(q.ll > 32 || (q.plain && q.ml > 32));
-            q.hp = (q.staged && prevStaged && prevEnd + q.total <= kOutHist) ? prevEnd : 0u;
+            // the batch goes right behind the previous one; when the stage is full the last kOutKeep bytes of history move to
+            // the front first (`shift` = how far)
+            q.hp = (q.staged && prevStaged) ? (prevEnd + q.total <= kOutHist ? prevEnd : (prevEnd < kOutKeep ? prevEnd : kOutKeep)) : 0u;
+            q.shift = (q.staged && prevStaged) ? prevEnd - q.hp : 0u;
             q.nearS = fetchable && (uint64_t)(-ms) <= q.hp;          // source inside the history: no fetch
             q.fastS = fetchable && !q.nearS;
             return q;
@@ -2212,6 +2217,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
             if (staged) {
                 // ---- literals and fetched match bytes into LDS, then every run into its place in the output stage
                 lds_sync();       // the previous batch's reads of the stages are done
+                if (pl.shift) {
+                    // (source above destination, 1 KB per pass, every pass reads before it writes: what a pass overwrites has been read)
+                    uint32_t const sh = pl.shift;
+                    for (uint32_t o = 16 * lane; o < hp; o += 1024) {
+                        uint4 x;
+                        __builtin_memcpy(&x, outStage + sh + o, 16);       // (may run past the history's end into bytes nobody uses)
+                        __builtin_memcpy(outStage + o, &x, 16);
+                    }
+                }
                 if (litRle) *(uint4*)(litStage + 16 * lane) = make_uint4(rleFill, rleFill, rleFill, rleFill);
                 else {
                     if (lane < litFull) *(uint4*)(litStage + 16 * lane) = litV;
