@@ -1382,6 +1382,9 @@ __global__ __launch_bounds__(kSeqThreads) void k_sequences(BatchParams p)
     __shared__ uint32_t activeFlag[2];         // per round parity: some block still has sequences to decode in that round
     __shared__ uint32_t zeroCell;              // the "table" of a block's fourth chain lane: its cell adds nothing to the sum of the quad
     uint32_t const tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+#ifdef ZG_STAMPS
+    uint64_t const k0 = __builtin_readcyclecounter(); uint64_t kSetup = 0, kLoop = 0, kRounds = 0;
+#endif
     if (tid < 36) { sLLbase[tid] = c_LL_base[tid]; sLLbits[tid] = c_LL_bits[tid]; }
     if (tid < 53) { sMLbase[tid] = c_ML_base[tid]; sMLbits[tid] = c_ML_bits[tid]; }
     if (tid == 0) { activeFlag[0] = 1; activeFlag[1] = 0; zeroCell = 0; }
@@ -1548,6 +1551,9 @@ __global__ __launch_bounds__(kSeqThreads) void k_sequences(BatchParams p)
     uint4* const out = (uint4*)p.seqBuf + blk.seqBufOff;
     uint4* const trash = out + nbSeq + 1;      // 64 spare records per block take the stores of lanes without a sequence
 
+#ifdef ZG_STAMPS
+    kSetup = __builtin_readcyclecounter() - k0;
+#endif
     for (uint32_t k = 0;; k++) {
         uint32_t const par = k & 1;
         bool const act = activeFlag[par] != 0;
@@ -1574,6 +1580,9 @@ __global__ __launch_bounds__(kSeqThreads) void k_sequences(BatchParams p)
                     uint32_t T = Q - 95, a0, a1, a2, a3;
                     win_read(T, a0, a1, a2, a3);
                     uint32_t c = *(lds_u32)(uintptr_t)(tabL + 4 * st);
+#ifdef ZG_STAMPS
+                    uint64_t const kl0 = __builtin_readcyclecounter();
+#endif
                     for (; i < kSeqRound; i += 8) {
                         if (T < Tlim) break;
                         // Past the block's last sequence the chain runs on over bits that mean nothing, inside the window
@@ -1608,6 +1617,9 @@ __global__ __launch_bounds__(kSeqThreads) void k_sequences(BatchParams p)
                             __builtin_amdgcn_sched_barrier(0);
                         }
                     }
+#ifdef ZG_STAMPS
+                    kLoop += __builtin_readcyclecounter() - kl0; kRounds++;
+#endif
                     n = i < remaining ? i : remaining;
                     Q = (n < i ? ring[4 * n + 3] : T) + 95;
                     remaining -= n;
@@ -1742,6 +1754,12 @@ __global__ __launch_bounds__(kSeqThreads) void k_sequences(BatchParams p)
         wg_barrier();
         if (!act || k > (1u << 16)) break;     // (every round with work left decodes at least 8 sequences of each unfinished block)
     }
+#ifdef ZG_STAMPS
+    if (chain && hasJob && role == 0 && p.dbg) {      // diagnostic build: where the chain wave's cycles went
+        uint64_t* const q = p.dbg + 8 * (size_t)p.nBlocks + 8 * (size_t)b;
+        q[0] = kSetup; q[1] = kLoop; q[2] = __builtin_readcyclecounter() - k0; q[3] = kRounds; q[4] = ctl[slot].nbSeq;
+    }
+#endif
     wave_sync();         // the round stores are complete before the end record goes on top of one of them
     if (helper && hasJob && gl == 0) {
         DevBlockState* const st = p.state + b;

@@ -691,6 +691,12 @@ extern "C" size_t zstdgpu_batch_decode(zstdgpu_batch* B, const void* devSrc, voi
                 if ((q[12] & 7) && shown < 6) { fprintf(stderr, "[stamps] split decode block %zu: why 0x%llx sum %llu want %llu idx/valid %llx\n", i, (unsigned long long)q[12], (unsigned long long)q[13], (unsigned long long)q[14], (unsigned long long)q[15]); shown++; } }
             for (int w = 0; w < 128; w++) if (hist[w]) fprintf(stderr, "[stamps] split decode why 0x%x: %zu blocks\n", w, hist[w]);
         }
+        {   // sequence stage: the blocks with the most sequences
+            double u[5] = {0}; size_t m = 0; uint64_t big = 0;
+            for (size_t i = 0; i < p.nBlocks; i++) { const uint64_t* q = h.data() + 8 * p.nBlocks + 8 * i; if (q[4] > big) big = q[4]; }
+            for (size_t i = 0; i < p.nBlocks; i++) { const uint64_t* q = h.data() + 8 * p.nBlocks + 8 * i; if (q[4] && q[4] * 100 >= big * 99) { for (int j = 0; j < 5; j++) u[j] += q[j]; m++; } }
+            if (m) fprintf(stderr, "[stamps] k_sequences, %zu longest blocks (%.0f sequences): setup %.0f  in chain loop %.0f  whole kernel %.0f ticks; %.0f rounds\n", m, u[4] / m, u[0] / m, u[1] / m, u[2] / m, u[3] / m);
+        }
         double t[8] = {0}; size_t n = 0;
         for (size_t i = 0; i < p.nFrames; i++) if (h[8 * i + 5]) { for (int j = 0; j < 8; j++) t[j] += h[8 * i + j]; n++; }
         if (n) fprintf(stderr, "[stamps] k_execute per frame: setup %.0f  load-issue %.0f  load-wait %.0f  assemble+store %.0f  rest %.0f ticks; %.0f batches, %.0f extra passes, %.0f staged\n",
