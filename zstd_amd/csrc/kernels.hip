@@ -72,6 +72,25 @@ DEVI uint32_t rd32z(SrcT p, uint32_t size, uint32_t i)
         if (i + k < size) v |= (uint32_t)p[i + k] << (8 * k);
     return v;
 }
+// (one unaligned access when all four bytes exist)
+DEVI uint32_t rd32z(const uint8_t* p, uint32_t size, uint32_t i)
+{
+    if (i + 4 <= size) { uint32_t v; __builtin_memcpy(&v, p + i, 4); return v; }
+    return rd32z<const uint8_t*>(p, size, i);
+}
+
+// Bytes of a table description: the first nStaged of them were copied to LDS, the rest (rare) are read from memory.
+struct HdrBytes {
+    const uint8_t* lds;
+    const uint8_t* mem;
+    uint32_t nStaged;
+    DEVI uint8_t operator[](uint32_t i) const { return i < nStaged ? lds[i] : mem[i]; }
+};
+DEVI uint32_t rd32z(HdrBytes const& p, uint32_t size, uint32_t i)
+{
+    if (i + 4 <= size && i + 4 <= p.nStaged) { uint32_t v; __builtin_memcpy(&v, p.lds + i, 4); return v; }
+    return rd32z<HdrBytes const&>(p, size, i);
+}
 
 // Backward bit reader (BIT_DStream_t, common/bitstream.pas:40-51, :206-398) kept as a logical bit
 // position: `left()` bits of the stream remain unread.  The 64-bit window is re-read from global
@@ -169,6 +188,23 @@ DEVI void grp_stage_bytes(uint8_t* dst, const uint8_t* src, uint32_t n, uint32_t
         } else {
             for (uint32_t i = 0; i < n; i++) dst[i] = src[i];
         }
+    }
+}
+
+// n copies of a 1-byte or 2-byte value at dst (LDS, any alignment) by one lane: 16 bytes per store, the tail as a store
+// that ends with the last byte (a dominant symbol owns hundreds of cells: byte by byte, its lane would keep the group waiting)
+DEVI void fill_bytes(uint8_t* dst, uint32_t v32, uint32_t nBytes)
+{
+    uint4 const x = make_uint4(v32, v32, v32, v32);
+    if (nBytes >= 16) {
+        for (uint32_t i = 0; i + 16 <= nBytes; i += 16) __builtin_memcpy(dst + i, &x, 16);
+        // (for 2-byte values nBytes and every offset used are even, so the pattern stays in phase)
+        if (nBytes & 15) __builtin_memcpy(dst + nBytes - 16, &x, 16);
+    } else {
+        if (nBytes & 8) { __builtin_memcpy(dst, &x, 8); dst += 8; }
+        if (nBytes & 4) { __builtin_memcpy(dst, &x, 4); dst += 4; }
+        if (nBytes & 2) { __builtin_memcpy(dst, &x, 2); dst += 2; }
+        if (nBytes & 1) dst[0] = (uint8_t)v32;
     }
 }
 
@@ -589,8 +625,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
                 if (w) {
                     uint32_t const len = (1u << w) >> 1;
                     uint32_t const start = pos[n];
-                    uint16_t const cell = (uint16_t)(n | ((tableLog + 1 - w) << 8));
-                    for (uint32_t u = 0; u < len; u++) x1[start + u] = cell;
+                    uint32_t const cell = n | ((tableLog + 1 - w) << 8);
+                    fill_bytes((uint8_t*)(x1 + start), cell | (cell << 16), 2 * len);
                 }
             }
         }
@@ -1170,14 +1206,6 @@ DEVI uint32_t dev_desc_size(int t, uint32_t type, const uint8_t* payload, uint32
     return dev_readNCount(norm, maxSV, tableLog, payload + o, cSize - o);
 }
 
-// Bytes of a table description: the first nStaged of them from a copy in LDS, the rest from memory.
-struct HdrBytes {
-    const uint8_t* lds;
-    const uint8_t* mem;
-    uint32_t nStaged;
-    DEVI uint8_t operator[](uint32_t i) const { return i < nStaged ? lds[i] : mem[i]; }
-};
-
 // What the first lane of a group found for one table: how the 16 lanes fill it.
 enum : uint32_t { TK_FAIL = 0, TK_NORM = 1, TK_RLE = 2, TK_DICT = 3 };
 
@@ -1227,16 +1255,26 @@ constexpr uint32_t kGrpBuildScratch = 128 + 512 + 2048;
 DEVI void grp_build_seq_table(int t, uint32_t* cells, const int16_t* norm, uint32_t maxSV, uint32_t tableLog, uint8_t* scratch, uint32_t gl,
                               const uint8_t* llBits, const uint8_t* mlBits)
 {
+    // LDS reads are issued in batches of 8 or 16 ahead of the stores that depend on them: the loops below are chains of
+    // LDS round trips otherwise (the compiler keeps a load behind every earlier store that might alias it).
     uint16_t* const cum = (uint16_t*)scratch;
     uint8_t* const occ = scratch + 128;
     uint16_t* const cnt = (uint16_t*)(scratch + 128 + 512);
     uint32_t const tableSize = 1u << tableLog, mask = tableSize - 1, step = (tableSize >> 1) + (tableSize >> 3) + 3;
     if (gl == 0) {
         uint32_t high = tableSize - 1, acc = 0;
-        for (uint32_t s = 0; s <= maxSV; s++) {
-            int const n = norm[s];
-            if (n == -1) cells[high--] = s;
-            else { cum[s] = (uint16_t)acc; acc += (uint32_t)n; }
+        for (uint32_t s0 = 0; s0 <= maxSV; s0 += 8) {      // (norm[] has 64 entries: reading past maxSV is harmless)
+            int n[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) n[j] = norm[s0 + j];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                uint32_t const sym = s0 + j;
+                if (sym <= maxSV) {
+                    if (n[j] == -1) cells[high--] = sym;
+                    else { cum[sym] = (uint16_t)acc; acc += (uint32_t)n[j]; }
+                }
+            }
         }
         cum[63] = (uint16_t)high;      // (symbols go up to 52)
     }
@@ -1245,41 +1283,81 @@ DEVI void grp_build_seq_table(int t, uint32_t* cells, const int16_t* norm, uint3
     for (uint32_t s = gl; s <= maxSV; s += 16) {
         int const n = norm[s];
         uint32_t const c0 = cum[s];
-        for (int i = 0; i < n; i++) occ[c0 + i] = (uint8_t)s;
+        if (n > 0) fill_bytes(occ + c0, 0x01010101u * s, (uint32_t)n);
     }
     lds_sync();
-    uint32_t const C = tableSize >> 4, i0 = gl * C;       // tableSize >= 32
+    uint32_t const C = tableSize >> 4, i0 = gl * C;       // tableSize >= 32: C = 2, 4, 8, 16 or 32
     {
         uint32_t local = 0;
         for (uint32_t i = i0; i < i0 + C; i++) local += (((i * step) & mask) <= high) ? 1u : 0u;
         uint32_t incl = local;
         incl += dpp_or0<0x111, 0xF>(incl); incl += dpp_or0<0x112, 0xF>(incl); incl += dpp_or0<0x114, 0xF>(incl); incl += dpp_or0<0x118, 0xF>(incl);
         uint32_t r = incl - local;
-        for (uint32_t i = i0; i < i0 + C; i++) {
-            uint32_t const pos = (i * step) & mask;
-            if (pos <= high) { cells[pos] = occ[r]; r++; }
+        for (uint32_t g = 0; g < C; g += 8) {
+            // the next 8 symbols of the spread sequence (at most 8 are used by this group of steps)
+            uint32_t const w0 = occ[r] | (occ[r + 1] << 8) | (occ[r + 2] << 16) | ((uint32_t)occ[r + 3] << 24);
+            uint32_t const w1 = occ[r + 4] | (occ[r + 5] << 8) | (occ[r + 6] << 16) | ((uint32_t)occ[r + 7] << 24);
+            uint64_t w = ((uint64_t)w1 << 32) | w0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                uint32_t const i = i0 + g + j;
+                uint32_t const pos = (i * step) & mask;
+                if (g + j < C && pos <= high) { cells[pos] = (uint32_t)w & 255u; w >>= 8; r++; }
+            }
         }
     }
     for (uint32_t q = 0; q < 8; q++) *(uint4*)(cnt + 64 * gl + 8 * q) = make_uint4(0, 0, 0, 0);
     lds_sync();
-    for (uint32_t u = i0; u < i0 + C; u++) {
-        uint32_t const sym = cells[u];
-        uint32_t const c = cnt[64 * gl + sym];
-        cnt[64 * gl + sym] = (uint16_t)(c + 1);
-        cells[u] = sym | (c << 8);
+    for (uint32_t g = 0; g < C; g += 8) {
+        uint32_t sym[8], c[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) sym[j] = cells[i0 + (g + j < C ? g + j : 0u)];
+#pragma unroll
+        for (int j = 0; j < 8; j++) c[j] = cnt[64 * gl + sym[j]];
+        // occurrences of the same symbol earlier in this batch
+#pragma unroll
+        for (int j = 1; j < 8; j++) {
+#pragma unroll
+            for (int i = 0; i < j; i++) c[j] += (sym[i] == sym[j]) ? 1u : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            if (g + j < C) {
+                cnt[64 * gl + sym[j]] = (uint16_t)(c[j] + 1);      // (in order: the last occurrence leaves the final count)
+                cells[i0 + g + j] = sym[j] | (c[j] << 8);
+            }
+        }
     }
     lds_sync();
     for (uint32_t s = gl; s <= maxSV; s += 16) {
         int const n = norm[s];
         uint32_t run = n == -1 ? 1u : (uint32_t)n;
-        for (uint32_t l = 0; l < 16; l++) { uint32_t const c = cnt[64 * l + s]; cnt[64 * l + s] = (uint16_t)run; run += c; }
+        uint32_t c[16];
+#pragma unroll
+        for (int l = 0; l < 16; l++) c[l] = cnt[64 * l + s];
+#pragma unroll
+        for (int l = 0; l < 16; l++) { cnt[64 * l + s] = (uint16_t)run; run += c[l]; }
     }
     lds_sync();
-    for (uint32_t u = i0; u < i0 + C; u++) {
-        uint32_t const v = cells[u], sym = v & 255u;
-        uint32_t const ns = cnt[64 * gl + sym] + (v >> 8);
-        uint32_t const nb = tableLog - hb32(ns);
-        cells[u] = seq_cell(t, (ns << nb) - tableSize, nb, t == T_LL ? llBits[sym] : t == T_OF ? sym : mlBits[sym], sym);
+    for (uint32_t g = 0; g < C; g += 8) {
+        uint32_t v[8], k[8], ab[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = cells[i0 + (g + j < C ? g + j : 0u)];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            uint32_t const sym = v[j] & 255u;
+            k[j] = cnt[64 * gl + sym];
+            ab[j] = t == T_LL ? llBits[sym] : t == T_OF ? sym : mlBits[sym];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            if (g + j < C) {
+                uint32_t const sym = v[j] & 255u;
+                uint32_t const ns = k[j] + (v[j] >> 8);
+                uint32_t const nb = tableLog - hb32(ns);
+                cells[i0 + g + j] = seq_cell(t, (ns << nb) - tableSize, nb, ab[j], sym);
+            }
+        }
     }
     lds_sync();
 }
@@ -1427,13 +1505,19 @@ __global__ __launch_bounds__(kSeqThreads) void k_sequences(BatchParams p)
             uint32_t const nStaged = hdrAvail < 256 ? hdrAvail : 256;
             grp_stage_bytes(hdr, payload + off, nStaged, gl);
             lds_sync();
+#ifdef ZG_STAMPS
+            if (gl == 0 && p.dbg) p.dbg[8 * (size_t)p.nBlocks + 8 * (size_t)b + 5] = __builtin_readcyclecounter() - k0;
+#endif
             bool fail = false;
             uint32_t done = 0;          // description bytes consumed so far
-#pragma unroll
+#pragma unroll 1      // (one copy of this code run three times: it is executed once per block, and instruction fetch is what it costs)
             for (int t = 0; t < 3; t++) {
                 uint32_t const type = t == T_LL ? blk.llType : t == T_OF ? blk.ofType : blk.mlType;
                 int32_t const srcB = t == T_LL ? blk.llSrc : t == T_OF ? blk.ofSrc : blk.mlSrc;
                 uint32_t* const cells = t == T_LL ? tLL : t == T_OF ? tOF : tML;
+#ifdef ZG_STAMPS
+                uint64_t const kp0 = __builtin_readcyclecounter();
+#endif
                 if (gl == 0) {
                     uint32_t kind = TK_FAIL, maxSV = 0, lg = 0, used = 0;
                     if (fail) {
@@ -1466,6 +1550,9 @@ __global__ __launch_bounds__(kSeqThreads) void k_sequences(BatchParams p)
                     note[0] = kind; note[1] = maxSV; note[2] = lg; note[3] = used;
                 }
                 lds_sync();
+#ifdef ZG_STAMPS
+                if (gl == 0 && p.dbg) p.dbg[8 * (size_t)p.nBlocks + 8 * (size_t)b + 7] += __builtin_readcyclecounter() - kp0;
+#endif
                 uint32_t const kind = note[0], maxSV = note[1], lg = note[2];
                 done += note[3];
                 if (kind == TK_FAIL) fail = true;
@@ -1477,6 +1564,9 @@ __global__ __launch_bounds__(kSeqThreads) void k_sequences(BatchParams p)
                 logsPacked |= lg << (t == T_LL ? 0 : t == T_OF ? 8 : 16);
                 lds_sync();      // the note and the scratch are free again
             }
+#ifdef ZG_STAMPS
+            if (gl == 0 && p.dbg) p.dbg[8 * (size_t)p.nBlocks + 8 * (size_t)b + 6] = __builtin_readcyclecounter() - k0;
+#endif
             off += done;
             if (!fail && off >= blk.cSize) fail = true;                     // BIT_initDStream on an empty stream
             if (!fail && payload[blk.cSize - 1] == 0) fail = true;          // no end mark

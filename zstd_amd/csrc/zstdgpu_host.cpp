@@ -692,10 +692,10 @@ extern "C" size_t zstdgpu_batch_decode(zstdgpu_batch* B, const void* devSrc, voi
             for (int w = 0; w < 128; w++) if (hist[w]) fprintf(stderr, "[stamps] split decode why 0x%x: %zu blocks\n", w, hist[w]);
         }
         {   // sequence stage: the blocks with the most sequences
-            double u[5] = {0}; size_t m = 0; uint64_t big = 0;
+            double u[8] = {0}; size_t m = 0; uint64_t big = 0;
             for (size_t i = 0; i < p.nBlocks; i++) { const uint64_t* q = h.data() + 8 * p.nBlocks + 8 * i; if (q[4] > big) big = q[4]; }
-            for (size_t i = 0; i < p.nBlocks; i++) { const uint64_t* q = h.data() + 8 * p.nBlocks + 8 * i; if (q[4] && q[4] * 100 >= big * 99) { for (int j = 0; j < 5; j++) u[j] += q[j]; m++; } }
-            if (m) fprintf(stderr, "[stamps] k_sequences, %zu longest blocks (%.0f sequences): setup %.0f  in chain loop %.0f  whole kernel %.0f ticks; %.0f rounds\n", m, u[4] / m, u[0] / m, u[1] / m, u[2] / m, u[3] / m);
+            for (size_t i = 0; i < p.nBlocks; i++) { const uint64_t* q = h.data() + 8 * p.nBlocks + 8 * i; if (q[4] && q[4] * 100 >= big * 99) { for (int j = 0; j < 8; j++) u[j] += q[j]; m++; } }
+            if (m) fprintf(stderr, "[stamps] k_sequences, %zu longest blocks (%.0f sequences): setup %.0f (descriptions staged at %.0f, tables built at %.0f, of which descriptions parsed by one lane %.0f)  in chain loop %.0f  whole kernel %.0f ticks; %.0f rounds\n", m, u[4] / m, u[0] / m, u[5] / m, u[6] / m, u[7] / m, u[1] / m, u[2] / m, u[3] / m);
         }
         double t[8] = {0}; size_t n = 0;
         for (size_t i = 0; i < p.nFrames; i++) if (h[8 * i + 5]) { for (int j = 0; j < 8; j++) t[j] += h[8 * i + j]; n++; }
