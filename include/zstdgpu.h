@@ -106,6 +106,22 @@ typedef struct {
     uint64_t regenSize;     /* bytes written at dstOff */
 } zstdgpu_frame_status;
 
+/* ---- streaming (ZSTD_decompressStream and friends, decompress/zstd_decompressf.pas:1510-1637, :1978-2359)
+ * A host state machine in front of the one-shot path: input is collected until one whole frame is present (its
+ * size is found by following the block headers as they arrive), the frame is decoded on the GPU, and its output is
+ * handed over as room is given.  Return value as in the reference: 0 when a frame has been decoded and flushed
+ * completely, a positive hint while more input or more room is needed, or an error (sticky until the stream is
+ * re-initialised).  Skippable frames are consumed and regenerate nothing. */
+typedef struct zstdgpu_dstream zstdgpu_dstream;
+typedef struct { const void* src; size_t size; size_t pos; } zstdgpu_inBuffer;     /* ZSTD_inBuffer */
+typedef struct { void* dst; size_t size; size_t pos; } zstdgpu_outBuffer;          /* ZSTD_outBuffer */
+zstdgpu_dstream* zstdgpu_createDStream(zstdgpu_ctx* ctx);                          /* ZSTD_createDStream :1510 */
+void   zstdgpu_freeDStream(zstdgpu_dstream* zds);                                  /* ZSTD_freeDStream :1526 */
+size_t zstdgpu_initDStream(zstdgpu_dstream* zds);                                  /* ZSTD_initDStream :1605 */
+size_t zstdgpu_initDStream_usingDDict(zstdgpu_dstream* zds, const zstdgpu_ddict* ddict);   /* :1614 */
+size_t zstdgpu_resetDStream(zstdgpu_dstream* zds);                                 /* ZSTD_resetDStream :1630 */
+size_t zstdgpu_decompressStream(zstdgpu_dstream* zds, zstdgpu_outBuffer* output, zstdgpu_inBuffer* input);   /* :1978 */
+
 /* One source frame of a batch: where it is and where its output goes. */
 typedef struct {
     uint64_t srcOff, srcSize, dstOff, dstCapacity;

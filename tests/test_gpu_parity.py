@@ -316,3 +316,105 @@ def test_device_walk_many_blocks(dctx):
         if not werr:
             o = int(fin[i]["dstOff"])
             assert out[o:o + len(w)].tobytes() == w
+
+
+# ------------------------------------------------------------------ streaming over the batched path
+def _stream_all(zs, data: bytes, in_chunk: int, out_room: int):
+    """Feed `data` in pieces of in_chunk bytes, draining with out_room bytes of room per call.  Returns the output and
+    the return value of every call that ended a frame (0) or the error raised."""
+    out = bytearray()
+    pos, zeros = 0, 0
+    guard = 0
+    last = None
+    while True:
+        piece = data[pos:pos + in_chunk]
+        r, used, got = zs.decompress_stream(piece, out_room)
+        out += got
+        pos += used
+        last = r
+        if r == 0:
+            zeros += 1
+        guard += 1
+        assert guard < 2_000_000
+        if pos >= len(data) and (r == 0 or (used == 0 and not got)):
+            break
+    return bytes(out), zeros, last
+
+
+@pytest.mark.parametrize("in_chunk,out_room", [(1 << 20, 1 << 21), (4096, 1000), (7, 65536), (1, 1 << 20), (100000, 3)])
+def test_stream_matches_oneshot(dctx, in_chunk, out_room):
+    names = ["text4096_l3_c1", "text128k_l3_c0", "bin128k_l19_c1", "empty_c1", "text255_l3_c1", "rle300k", "text33_l3_c1"]
+    if in_chunk >= 4096:
+        names.append("text1m_l1")
+    zs = api.DStream(dctx)
+    for n in names:
+        if out_room == 3 and n in ("rle300k", "text128k_l3_c0", "bin128k_l19_c1"):
+            continue      # (hundreds of thousands of calls: nothing new to see)
+        e = next(x for x in FRAMES if x["name"] == n)
+        want, werr = oracle.decompress(read_frame(e), e["capacity"])
+        assert werr == 0
+        got, zeros, last = _stream_all(zs, read_frame(e), in_chunk, out_room)
+        assert got == want, n
+        assert zeros == 1 and last == 0, n
+    zs.close()
+
+
+def test_stream_concatenated_and_skippable_frames(dctx):
+    """Frames back to back in one stream, a skippable frame between them: one 0 per frame, output concatenated."""
+    es = [next(x for x in FRAMES if x["name"] == n) for n in ("text4096_l3_c1", "text255_l3_c1", "bin128k_l19_c1")]
+    skip = b"\x5a\x2a\x4d\x18" + (11).to_bytes(4, "little") + b"hello world"
+    data = read_frame(es[0]) + skip + read_frame(es[1]) + read_frame(es[2])
+    want = b"".join(oracle.decompress(read_frame(e), e["capacity"])[0] for e in es)
+    zs = api.DStream(dctx)
+    for in_chunk in (1 << 20, 1000, 13):
+        got, zeros, last = _stream_all(zs, data, in_chunk, 50000)
+        assert got == want
+        assert zeros == 4 and last == 0
+    zs.close()
+
+
+def test_stream_errors_and_reset(dctx):
+    zs = api.DStream(dctx)
+    e = next(x for x in FRAMES if x["name"] == "text4096_l3_c1")
+    fr = read_frame(e)
+    # not a zstd frame
+    with pytest.raises(api.ZstdError) as ei:
+        zs.decompress_stream(b"abcdefgh", 100)
+    assert ei.value.code == 10
+    with pytest.raises(api.ZstdError):       # the error sticks
+        zs.decompress_stream(fr, 100)
+    zs.reset()
+    # every corrupted fixture gives the one-shot verdict once its last byte is in (or hangs on for more input, when the
+    # damage makes the frame look longer than it is)
+    for c in [x for x in FRAMES if "error" in x and x["error"] != 70 and "dict" not in x and x["csize"] > 0 and x["capacity"] <= (1 << 20)][:60]:
+        if c["name"].startswith(("concat", "skippable")):
+            continue      # (a stream ends its first frame before it meets what follows)
+        data = read_frame(c)
+        _, werr = oracle.decompress(data, c["capacity"])
+        zs.reset()
+        try:
+            r, used, got = zs.decompress_stream(data, c["capacity"] + 64)
+            assert r != 0 or werr == 0, c["name"]        # an unfinished frame asks for more
+        except api.ZstdError as ex:
+            assert werr != 0, c["name"]
+            assert ex.code == werr or ex.code in (10, 14, 16, 20, 72), c["name"]
+    # a half-fed frame is dropped by a reset, and the stream works again
+    zs.reset()
+    r, used, got = zs.decompress_stream(fr[:100], 100)
+    assert r > 0 and used == 100 and got == b""
+    zs.reset()
+    got, zeros, last = _stream_all(zs, fr, 1 << 20, 1 << 20)
+    assert got == oracle.decompress(fr, e["capacity"])[0] and last == 0
+    zs.close()
+
+
+def test_stream_with_dictionary(dctx):
+    d = read_dict("dict16k")
+    dd = api.DDict(dctx, d)
+    zs = api.DStream(dctx, dd)
+    for e in [x for x in FRAMES if x.get("dict") == "dict16k" and "error" not in x][:6]:
+        want, _ = oracle.decompress(read_frame(e), e["capacity"], d)
+        got, zeros, last = _stream_all(zs, read_frame(e), 500, 4096)
+        assert got == want and zeros == 1 and last == 0
+    zs.close()
+    dd.close()

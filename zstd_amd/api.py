@@ -63,6 +63,8 @@ EXPORTS = (
     "zstdgpu_decompress", "zstdgpu_decompressDCtx", "zstdgpu_decompress_usingDict", "zstdgpu_decompress_usingDDict",
     "zstdgpu_buildDescriptors", "zstdgpu_batch_create", "zstdgpu_batch_create_from_frames", "zstdgpu_batch_create_on_device",
     "zstdgpu_batch_descriptorDigest", "zstdgpu_batch_destroy",
+    "zstdgpu_createDStream", "zstdgpu_freeDStream", "zstdgpu_initDStream", "zstdgpu_initDStream_usingDDict", "zstdgpu_resetDStream",
+    "zstdgpu_decompressStream",
     "zstdgpu_batch_decode", "zstdgpu_batch_status", "zstdgpu_batch_nFrames", "zstdgpu_batch_nBlocks", "zstdgpu_batch_srcBytes",
     "zstdgpu_batch_scratchBytes", "zstdgpu_batch_set_profiling", "zstdgpu_batch_stage_ms", "zstdgpu_stage_kernel_name",
     "zstdgpu_xxh64Batch", "zstdgpu_batch_blockInfo", "zstdgpu_batch_copyLiterals", "zstdgpu_batch_copySequences",
@@ -106,6 +108,12 @@ def lib():
     proto("zstdgpu_batch_create_from_frames", vp, vp, vp, sz, vp, u32, vp)
     proto("zstdgpu_batch_create_on_device", vp, vp, vp, sz, vp, u32, vp)
     proto("zstdgpu_batch_descriptorDigest", ctypes.c_uint64, vp)
+    proto("zstdgpu_createDStream", vp, vp)
+    proto("zstdgpu_freeDStream", None, vp)
+    proto("zstdgpu_initDStream", sz, vp)
+    proto("zstdgpu_initDStream_usingDDict", sz, vp, vp)
+    proto("zstdgpu_resetDStream", sz, vp)
+    proto("zstdgpu_decompressStream", sz, vp, vp, vp)
     proto("zstdgpu_batch_destroy", None, vp)
     proto("zstdgpu_batch_decode", sz, vp, vp, vp, vp)
     proto("zstdgpu_batch_status", sz, vp, vp)
@@ -342,3 +350,45 @@ def pack_frames(frames, capacities=None, align: int = 16):
         o = int(fin[i]["srcOff"])
         src[o:o + len(fr)] = np.frombuffer(fr, dtype=np.uint8)
     return src, fin, do + 64
+
+
+class _InBuffer(ctypes.Structure):
+    _fields_ = [("src", ctypes.c_void_p), ("size", ctypes.c_size_t), ("pos", ctypes.c_size_t)]
+
+
+class _OutBuffer(ctypes.Structure):
+    _fields_ = [("dst", ctypes.c_void_p), ("size", ctypes.c_size_t), ("pos", ctypes.c_size_t)]
+
+
+class DStream:
+    """ZSTD_DStream over the batched path (zstdgpu_decompressStream)."""
+
+    def __init__(self, dctx: DCtx, ddict: DDict = None):
+        self.dctx, self.ddict = dctx, ddict
+        self.h = lib().zstdgpu_createDStream(dctx.h)
+        if not self.h:
+            raise ZstdError(64)
+        _check(lib().zstdgpu_initDStream_usingDDict(self.h, ddict.h) if ddict else lib().zstdgpu_initDStream(self.h))
+
+    def reset(self):
+        _check(lib().zstdgpu_resetDStream(self.h))
+
+    def decompress_stream(self, data: bytes, out_room: int):
+        """One call of ZSTD_decompressStream: returns (return value, bytes consumed, bytes produced)."""
+        src = ctypes.create_string_buffer(data, len(data)) if data else ctypes.create_string_buffer(1)
+        dst = ctypes.create_string_buffer(max(out_room, 1))
+        ib = _InBuffer(ctypes.cast(src, ctypes.c_void_p), len(data), 0)
+        ob = _OutBuffer(ctypes.cast(dst, ctypes.c_void_p), out_room, 0)
+        r = _check(lib().zstdgpu_decompressStream(self.h, ctypes.byref(ob), ctypes.byref(ib)))
+        return r, ib.pos, dst.raw[:ob.pos]
+
+    def close(self):
+        if self.h:
+            lib().zstdgpu_freeDStream(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

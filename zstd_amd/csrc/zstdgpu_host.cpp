@@ -3,6 +3,7 @@
 // dictionary upload, batch management, and the one-shot drop-ins.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -938,6 +939,117 @@ extern "C" size_t zstdgpu_decompress_usingDict(zstdgpu_ctx* ctx, void* dst, size
     zstdgpu_freeDDict(d);
     return r;
 }
+
+// ===================================================================== streaming over the batched path
+// ZSTD_decompressStream (decompress/zstd_decompressf.pas:1978-2359) as a host state machine in front of the one-shot
+// path: the reference decodes block by block as input arrives; the kernels here want whole frames, so the stream
+// collects one frame (its size is found by following the block headers as they arrive, the loop of
+// ZSTD_findFrameSizeInfo, :566-639), decodes it, and hands the output over as room is given.  Results are the
+// reference's: the same bytes, 0 returned when a frame has been decoded and flushed completely, a positive hint while
+// more input or more room is needed, the same error codes.
+struct zstdgpu_dstream {
+    zstdgpu_ctx* ctx = nullptr;
+    const zstdgpu_ddict* ddict = nullptr;
+    std::vector<uint8_t> in, out;
+    size_t want = 5;          // bytes of `in` needed before the next decision (ZSTD_FRAMEHEADERSIZE_PREFIX to begin with)
+    size_t cursor = 0;        // offset of the next block header in `in` (0: frame header not seen yet)
+    size_t blocks = 0;        // blocks seen
+    bool checksum = false, skippable = false, lastSeen = false;
+    uint64_t contentSize = ZSTDGPU_CONTENTSIZE_UNKNOWN, windowSize = 0;
+    size_t outPos = 0;
+    bool flushing = false;
+    size_t error = 0;         // sticky until the stream is reset
+    void reset() { in.clear(); out.clear(); want = 5; cursor = 0; blocks = 0; checksum = skippable = lastSeen = false;
+                   contentSize = ZSTDGPU_CONTENTSIZE_UNKNOWN; windowSize = 0; outPos = 0; flushing = false; error = 0; }
+};
+
+extern "C" zstdgpu_dstream* zstdgpu_createDStream(zstdgpu_ctx* ctx)
+{
+    if (!ctx) return nullptr;
+    zstdgpu_dstream* z = new (std::nothrow) zstdgpu_dstream;
+    if (z) z->ctx = ctx;
+    return z;
+}
+extern "C" void zstdgpu_freeDStream(zstdgpu_dstream* z) { delete z; }
+// ZSTD_initDStream / ZSTD_initDStream_usingDDict (:1605-1628): start a new stream; returns the first input size hint
+extern "C" size_t zstdgpu_initDStream(zstdgpu_dstream* z) { if (!z) return mkerr(E_generic); z->reset(); z->ddict = nullptr; return 5; }
+extern "C" size_t zstdgpu_initDStream_usingDDict(zstdgpu_dstream* z, const zstdgpu_ddict* ddict) { if (!z) return mkerr(E_generic); z->reset(); z->ddict = ddict; return 5; }
+// ZSTD_resetDStream (:1630-1637): forget a half-read frame, keep the dictionary
+extern "C" size_t zstdgpu_resetDStream(zstdgpu_dstream* z) { if (!z) return mkerr(E_generic); z->reset(); return 5; }
+
+extern "C" size_t zstdgpu_decompressStream(zstdgpu_dstream* z, zstdgpu_outBuffer* output, zstdgpu_inBuffer* input)
+{
+    if (!z || !output || !input) return mkerr(E_generic);
+    if (input->pos > input->size) return mkerr(E_srcSize_wrong);       // :1994-2003
+    if (output->pos > output->size) return mkerr(E_dstSize_tooSmall);
+    if (z->error) return z->error;
+    auto fail = [&](uint32_t code) { z->error = mkerr(code); return z->error; };
+    for (;;) {
+        if (z->flushing) {
+            size_t const n = std::min(z->out.size() - z->outPos, output->size - output->pos);
+            if (n) memcpy((uint8_t*)output->dst + output->pos, z->out.data() + z->outPos, n);
+            output->pos += n; z->outPos += n;
+            if (z->outPos < z->out.size()) return z->out.size() - z->outPos;      // more room needed
+            z->reset();                                                           // (keeps the dictionary)
+            return 0;                                                             // frame done
+        }
+        // collect what the next decision needs
+        if (z->in.size() < z->want) {
+            size_t const n = std::min(z->want - z->in.size(), input->size - input->pos);
+            z->in.insert(z->in.end(), (const uint8_t*)input->src + input->pos, (const uint8_t*)input->src + input->pos + n);
+            input->pos += n;
+            if (z->in.size() < z->want) return z->want - z->in.size();            // more input needed
+        }
+        const uint8_t* const p = z->in.data();
+        if (z->cursor == 0 && !z->skippable) {
+            // frame start: magic, then the whole frame header
+            if (z->in.size() >= 4 && (rd32(p) & kMagicSkipMask) == kMagicSkipStart) {
+                if (z->in.size() < 8) { z->want = 8; continue; }
+                uint32_t const sz = rd32(p + 4);
+                if ((uint32_t)(sz + 8) < sz) return fail(E_frameParameter_unsupported);
+                z->skippable = true; z->want = (size_t)8 + sz;
+                continue;
+            }
+            if (z->in.size() >= 4 && rd32(p) != kMagic) return fail(E_prefix_unknown);
+            size_t const fhsize = frame_header_size(p, z->in.size());
+            if (z->in.size() < fhsize) { z->want = fhsize; continue; }
+            FrameHeader fh;
+            size_t const r = get_frame_header(fh, p, z->in.size());
+            if (iserr(r)) return fail((uint32_t)(0 - r));
+            if (fh.windowSize > ((1ull << 27) + 1)) return fail(E_frameParameter_windowTooLarge);     // ZSTD_MAXWINDOWSIZE_DEFAULT (:51, :2166)
+            z->checksum = fh.checksumFlag != 0; z->contentSize = fh.contentSize; z->windowSize = fh.windowSize;
+            z->cursor = fhsize; z->want = fhsize + 3;
+            continue;
+        }
+        if (z->skippable) {      // a skippable frame has arrived whole: it regenerates nothing (:885-893)
+            z->flushing = true; z->out.clear(); z->outPos = 0;
+            continue;
+        }
+        if (!z->lastSeen) {
+            // the block header at `cursor` is here: it tells where the next one is (ZSTD_getcBlockSize, zstd_decompress_block.pas:190-207)
+            uint32_t const hdr = rd24(p + z->cursor);
+            uint32_t const type = (hdr >> 1) & 3, size = hdr >> 3;
+            if (type == 3) return fail(E_corruption);
+            size_t const cSize = type == BT_RLE ? 1 : size;
+            z->blocks++;
+            z->cursor += 3 + cSize;
+            if (hdr & 1) { z->lastSeen = true; z->want = z->cursor + (z->checksum ? 4 : 0); }
+            else z->want = z->cursor + 3;
+            continue;
+        }
+        // the frame is complete: decode it
+        {
+            uint64_t const bound = z->contentSize != ZSTDGPU_CONTENTSIZE_UNKNOWN ? z->contentSize : (uint64_t)z->blocks * kBlockSizeMax;
+            if (bound > 0x7FFFFFFEull) return fail(E_memory_allocation);
+            z->out.resize((size_t)bound);
+            size_t const r = decompress_multi(z->ctx, z->out.data(), z->out.size(), p, z->in.size(), z->ddict);
+            if (iserr(r)) { z->error = r; return r; }
+            z->out.resize(r);
+            z->outPos = 0; z->flushing = true;
+        }
+    }
+}
+
 // ZSTD_decompress creates and frees its own context per call (zstd_decompressf.pas:977-988)
 extern "C" size_t zstdgpu_decompress(void* dst, size_t dstCapacity, const void* src, size_t srcSize)
 {
