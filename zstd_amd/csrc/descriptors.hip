@@ -245,7 +245,7 @@ __global__ __launch_bounds__(64) void k_fill_blocks(const uint8_t* src, uint64_t
                 if (d.litType == SET_COMPRESSED) d.hufSrc = hufDef = (int32_t)b;
                 if (d.litType >= SET_COMPRESSED) {
                     d.litBufOff = (d.litSize + 15) & ~15ull;
-                    if (!d.singleStream) d.litTmpOff = 16ull * litTmpLane(d.litSize);
+                    if (!d.singleStream) d.litTmpOff = litTmpBytes(d.litSize);
                     fl |= 1;
                 }
                 if (d.hostSeqErr) dead = true;

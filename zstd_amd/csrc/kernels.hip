@@ -514,8 +514,8 @@ constexpr int kHufLanes = 16;                // lanes per literal job: 4 decode 
 constexpr int kHufJobs = 64 / kHufLanes;     // jobs per wave
 constexpr uint32_t kHufTabBytes = 8192;      // 2^12 cells of {byte, nbBits}
 constexpr uint32_t kHufRound = 128;          // symbols per stream per round
-constexpr uint32_t kPackTabEntries = 17;    // per literal job: 16 parts + a flag
-constexpr uint32_t kSpecZone = 2048;        // split decode: bits in which neighbouring parts look for a common code boundary
+constexpr uint32_t kSpecParts = 8;          // split decode: parts per stream
+constexpr uint32_t kPackTabEntries = 4 * kSpecParts + 1;    // per literal job: 32 parts + a flag
 constexpr uint32_t kSpecRound = 32;         // split decode: symbols per lane per round
 constexpr uint32_t kSpecWinDw = 24;         // split decode: staged input per lane (6 units): 32 symbols x <= 12 bits + alignment slack
 constexpr uint32_t kHufInDw = 96;            // staged input per stream per round (24 units): 128 symbols x <=12 bits + alignment slack
@@ -676,244 +676,283 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
     uintptr_t const floorAddr = (uintptr_t)p.src;
     uint32_t const shift = 32 - tableLog;
     uint32_t done = 0;                            // symbols of my stream already decoded
-    // ---- split decode: four lanes per stream.
+    // ---- split decode: every stream in eight parts, two parts per lane.
     // A Huffman stream can only be decoded from its first code, but a decoder started at an arbitrary bit falls into
-    // step with the true code boundaries after a few symbols.  Lane (stream k, part j) starts at bit j/4 of the stream
-    // and decodes into a scratch region of its own.  While it is in the first kSpecZone bits of its part it marks the
-    // code boundaries it visits in a bitmap (LDS).  When it reaches the next part it looks its own boundaries up in
-    // that part's bitmap: at the first one found there the two decoders have met, the next part is on the true path
-    // from there on (part 0 is from its start), and this lane stops.  A lane that crosses the whole zone without
-    // meeting the next part carries on through that part (whose own output is then dropped) towards the part after
-    // it.  Popcounts of the bitmaps tell how many symbols of a part came before it was on the true path; a final copy
-    // packs the parts into the literal buffer.  If the totals disagree with the stream's symbol count, or a scratch
-    // region overflows, the block is decoded again stream by stream below (which also yields the verdict for corrupt
-    // streams).
+    // step with the true code boundaries after a few symbols.  Part P of stream k starts at bit P/8 of the stream and is
+    // decoded into a scratch region of its own; a lane runs parts j and j + 4 of its stream side by side, so that the
+    // table lookups of one fill the LDS round trips of the other.  At the start of each of its first 16 rounds (of 32
+    // symbols) a part notes where it is.  A decoder that has reached the next part compares its own code boundaries with
+    // those notes: at the first one it hits, the two decoders have met, the next part is on the true path from there on
+    // (part 0 is from its start), and this decoder stops.  One that gets past all 16 notes without a hit carries on
+    // through that part (whose own output is then dropped) towards the part after it.  A final copy packs the parts into
+    // the literal buffer.  If the totals disagree with the stream's symbol count, or a scratch region overflows, the
+    // block is decoded again stream by stream below (which also yields the verdict for corrupt streams).
     bool specDone = false;
     {
         uint32_t const k = sl & 3, j = sl >> 2;
         int T = 0;
-        bool sbad = !ok || nStreams != 4 || p.litTmp == nullptr || mySize == 0 || tableLog > 11;    // (a 2^12 table leaves no LDS for the bitmaps)
+        bool sbad = !ok || nStreams != 4 || p.litTmp == nullptr || mySize == 0 || tableLog > 11;    // (a 2^12 table leaves no LDS for the windows)
         if (!sbad) {
             uint32_t const last = myStart[mySize - 1];
             if (last == 0) sbad = true;
             else T = (int)(mySize * 8) - (int)(8 - hb32(last));
         }
-        if (T < (int)(4 * (2 * kSpecZone + 64))) sbad = true;       // parts long enough that the zones stay apart
+        if (T < (int)(kSpecParts * 1024)) sbad = true;       // (parts of at least 1024 bits)
         bool const eligible = ((__ballot(sbad) >> lead) & 0xFFFFu) == 0;
         if (eligible) {
-            constexpr uint32_t kMapDw = kSpecZone / 32;
-            static_assert(16 * 4 * kMapDw <= 4096, "bitmaps fit in the upper half of the table area");
-            uint32_t* const maps = (uint32_t*)(tab + 4096);            // [16 lanes][kMapDw]
-            uint32_t* const hbm = maps + sl * kMapDw;
-            for (uint32_t q = 0; q < kMapDw; q += 4) *(uint4*)(hbm + q) = make_uint4(0, 0, 0, 0);
-            auto boundary = [&](uint32_t t) -> int { return T - (int)((t * (uint32_t)T) >> 2); };     // first bit of part t (0 for t = 4)
-            int const Bj = boundary(j);
-            uint32_t t = j + 1;             // the part this lane is heading for (4: the end of the stream)
-            int Bt = boundary(t);
-            int cur = Bj;
-            uint32_t nDec = 0;              // symbols decoded by this lane
-            bool met = false, failed = false;
-            uint32_t upTo = 0, meetBit = 0; // symbols before the meeting point; its bit in the target's map
-            uint32_t const laneCap = litTmpLane(blk.litSize);
-            uint8_t* const tmpL = p.litTmp + blk.litTmpOff + (size_t)sl * laneCap;
-            uint32_t* const winL = inWin + sl * kSpecWinDw;
-            uint32_t* const soL = (uint32_t*)(outStage + sl * kSpecRound);
-            uintptr_t wbL = 0, pwb = 0;
-            uint4 pv[6];                    // the window requested during the previous round
+            // LDS of the job beyond the 4 KB table: notes [32 parts][16], windows [32][kSpecWinDw], output stages [32][kSpecRound]
+            uint16_t* const ckAll = (uint16_t*)(tab + 4096);
+            uint32_t* const winAll = (uint32_t*)(tab + 4096 + 1024);
+            uint8_t* const outAll = tab + 4096 + 1024 + 32 * 4 * kSpecWinDw;
+            static_assert(4096 + 1024 + 32 * 4 * kSpecWinDw + 32 * kSpecRound <= kHufJobBytes, "split decode fits in the job's LDS");
+            auto boundary = [&](uint32_t t) -> int { return T - (int)(((uint64_t)t * (uint32_t)T) >> 3); };     // first bit of part t (0 for t = 8)
+            uint32_t const laneCap = litTmpPart(blk.litSize);
+            // per part of this lane (c = 0, 1; constant indices once unrolled)
+            int cur[2], Bs[2], Bt[2];
+            uint32_t t[2], nDec[2], upTo[2], hdT[2], q[2], ckv[2], rem[2];
+            bool met[2], failed[2], prevActive[2];
+            uintptr_t wbL[2], pwb[2];
+            uint4 pv[2][6];                 // the windows requested during the previous round
+            uint8_t* tmpL[2]; uint32_t* winL[2]; uint32_t* soL[2]; uint16_t* ckL[2];
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                uint32_t const reg = sl + 16 * c, P = j + 4 * c;
+                Bs[c] = boundary(P); t[c] = P + 1; Bt[c] = boundary(P + 1); cur[c] = Bs[c];
+                nDec[c] = upTo[c] = hdT[c] = q[c] = rem[c] = 0; ckv[c] = 0xFFFFu;
+                met[c] = failed[c] = prevActive[c] = false;
+                wbL[c] = pwb[c] = 0;
+                tmpL[c] = p.litTmp + blk.litTmpOff + (size_t)reg * laneCap;
+                winL[c] = winAll + reg * kSpecWinDw;
+                soL[c] = (uint32_t*)(outAll + reg * kSpecRound);
+                ckL[c] = ckAll + 16 * reg;
+                *(uint4*)ckL[c] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);      // "not noted yet": matches nothing
+                *(uint4*)(ckL[c] + 8) = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+            }
             bool havePv = false;
-            bool prevActive = false;
-            uint32_t rem = 0;               // the 32 bits below the cursor, of which the top 20 or more are known from the last group
-#ifdef ZG_STAMPS
-            uint64_t zA = 0, zB = 0, zC = 0, zR = 0, zS = 0, zG = 0, zZ = 0; uint64_t const z0 = __builtin_readcyclecounter();
-#endif
             for (uint32_t r = 0;; r++) {
-#ifdef ZG_STAMPS
-                uint64_t const za = __builtin_readcyclecounter();
-#endif
-                bool const active = !met && !failed;
-                bool const anyActive = ((__ballot(active) >> lead) & 0xFFFFu) != 0;
-                // Window of this lane: 6 aligned units ending just above its unread bits.  Every round requests the window
-                // for the next one (placed at the cursor it starts from), so the load is over when it is needed; only when a
-                // round eats so much that this window cannot feed the next round is one loaded on the spot.
-                uintptr_t const wbCand = havePv ? pwb : wbL;
-                bool const low = active && (r == 0 || (int)(8 * (int64_t)((uintptr_t)myStart - wbCand)) + cur < (int)(tableLog * kSpecRound + 96));
-                bool const stage = anyActive && ((__ballot(low) >> lead) & 0xFFFFu) != 0;
-                uint4 v[6];
-                uintptr_t wbS = 0;
-                // (a window ends at the byte that holds the cursor: byte-aligned loads lose no more than 7 bits to alignment; only
-                // a window that would reach below the source buffer keeps to 16-byte units, which the clamp in the load needs)
-                auto window_base = [&]() -> uintptr_t {
-                    uintptr_t const top = (uintptr_t)myStart + (uintptr_t)((cur > 0 ? cur + 7 : 0) >> 3);
+                bool act[2];
+#pragma unroll
+                for (int c = 0; c < 2; c++) act[c] = !met[c] && !failed[c];
+                bool const anyActive = ((__ballot(act[0] || act[1]) >> lead) & 0xFFFFu) != 0;
+                // where each part is at the start of this round
+                if (r < 16) {
+#pragma unroll
+                    for (int c = 0; c < 2; c++) { uint32_t const d = (uint32_t)(Bs[c] - cur[c]); ckL[c][r] = (uint16_t)(d < 0xFFFEu ? d : 0xFFFEu); }
+                }
+                // Windows: 6 units per part ending at the byte that holds its cursor.  Every round requests the windows of the
+                // next one, so the load is over when it is needed; only when a round eats so much that such a window cannot feed
+                // the next round is one loaded on the spot.  (Byte-aligned loads lose at most 7 bits to alignment; a window that
+                // would reach below the source buffer keeps to 16-byte units, which the clamp in the load needs.)
+                auto window_base = [&](int cr) -> uintptr_t {
+                    uintptr_t const top = (uintptr_t)myStart + (uintptr_t)((cr > 0 ? cr + 7 : 0) >> 3);
                     uintptr_t const exact = top - 4 * kSpecWinDw;
                     return exact >= floorAddr ? exact : ((top + 15) & ~(uintptr_t)15) - 4 * kSpecWinDw;
                 };
-                if (stage) {
-                    wbS = window_base();
+                bool low = false;
 #pragma unroll
-                    for (int q = 0; q < 6; q++) v[q] = ld_unit_any(wbS + 16 * q, floorAddr);
+                for (int c = 0; c < 2; c++) {
+                    uintptr_t const wbCand = havePv ? pwb[c] : wbL[c];
+                    low = low || (act[c] && (r == 0 || (int)(8 * (int64_t)((uintptr_t)myStart - wbCand)) + cur[c] < (int)(tableLog * kSpecRound + 96)));
                 }
-                // the previous round's bytes go to the lane's scratch region
-                if (prevActive) {
-                    uint4 const x0 = *(const uint4*)soL, x1v = *(const uint4*)(soL + 4);
-                    __builtin_memcpy(tmpL + kSpecRound * (r - 1), &x0, 16);
-                    __builtin_memcpy(tmpL + kSpecRound * (r - 1) + 16, &x1v, 16);
+                bool const stage = anyActive && ((__ballot(low) >> lead) & 0xFFFFu) != 0;
+                uint4 v[2][6];
+                uintptr_t wbS[2] = {0, 0};
+                if (stage) {
+#pragma unroll
+                    for (int c = 0; c < 2; c++) {
+                        wbS[c] = window_base(cur[c]);
+#pragma unroll
+                        for (int u = 0; u < 6; u++) v[c][u] = ld_unit_any(wbS[c] + 16 * u, floorAddr);
+                    }
+                }
+                // the previous round's bytes go to the parts' scratch regions
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    if (prevActive[c]) {
+                        uint4 const x0 = *(const uint4*)soL[c], x1v = *(const uint4*)(soL[c] + 4);
+                        __builtin_memcpy(tmpL[c] + kSpecRound * (r - 1), &x0, 16);
+                        __builtin_memcpy(tmpL[c] + kSpecRound * (r - 1) + 16, &x1v, 16);
+                    }
                 }
                 if (!anyActive) break;
-#ifdef ZG_STAMPS
-                uint64_t const zb = __builtin_readcyclecounter();
-#endif
                 lds_sync();
-                if (stage) {
-                    wbL = wbS;
 #pragma unroll
-                    for (int q = 0; q < 6; q++) *(uint4*)(winL + 4 * q) = v[q];
-                } else if (havePv) {
-                    wbL = pwb;
+                for (int c = 0; c < 2; c++) {
+                    if (stage) {
+                        wbL[c] = wbS[c];
 #pragma unroll
-                    for (int q = 0; q < 6; q++) *(uint4*)(winL + 4 * q) = pv[q];
+                        for (int u = 0; u < 6; u++) *(uint4*)(winL[c] + 4 * u) = v[c][u];
+                    } else if (havePv) {
+                        wbL[c] = pwb[c];
+#pragma unroll
+                        for (int u = 0; u < 6; u++) *(uint4*)(winL[c] + 4 * u) = pv[c][u];
+                    }
                 }
                 lds_sync();
-                {   // the window the next round will start from
-                    pwb = window_base();
 #pragma unroll
-                    for (int q = 0; q < 6; q++) pv[q] = ld_unit_any(pwb + 16 * q, floorAddr);
-                    havePv = true;
+                for (int c = 0; c < 2; c++) {       // the windows the next round will start from
+                    pwb[c] = window_base(cur[c]);
+#pragma unroll
+                    for (int u = 0; u < 6; u++) pv[c][u] = ld_unit_any(pwb[c] + 16 * u, floorAddr);
                 }
-#ifdef ZG_STAMPS
-                uint64_t const zc = __builtin_readcyclecounter();
-                zA += zb - za; zB += zc - zb; zR += 1; zS += stage ? 1 : 0;
-#endif
-                prevActive = false;
-                if (active) {
-                    if (kSpecRound * (r + 1) > laneCap) failed = true;
-                    else {
-                        prevActive = true;
-                        int const Qbase = (int)(8 * (int64_t)((uintptr_t)myStart - wbL));
-                        if (r == 0) { uint32_t lo; peek64(winL, (uint32_t)(Qbase + cur), rem, lo); }
-                        // always the whole round (no lane-dependent exit from the loop): a lane that has met the part ahead, or
-                        // failed, decodes on harmlessly inside its window; what it produces past that point is never used
+                havePv = true;
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    prevActive[c] = false;
+                    if (act[c]) {
+                        if (kSpecRound * (r + 1) > laneCap) { failed[c] = true; act[c] = false; }
+                        else prevActive[c] = true;
+                    }
+                }
+                if (act[0] || act[1]) {
+                    int Qbase[2];
+#pragma unroll
+                    for (int c = 0; c < 2; c++) {
+                        Qbase[c] = (int)(8 * (int64_t)((uintptr_t)myStart - wbL[c]));
+                        if (r == 0) { uint32_t lo; peek64(winL[c], (uint32_t)(Qbase[c] + cur[c]), rem[c], lo); }
+                    }
+                    // Always the whole round: a part that has met the one ahead decodes on harmlessly inside its window; what it
+                    // produces past that point is never used.  A part that was not active when the round began stays where it is.
+                    // Most rounds no part of the wave can reach the part ahead of it (or the end of its stream): those rounds run
+                    // without any of the meeting logic.
+                    bool nearTarget = false;
+#pragma unroll
+                    for (int c = 0; c < 2; c++) nearTarget = nearTarget || (act[c] && cur[c] - (int)(tableLog * kSpecRound + 64) <= Bt[c]);
+                    if (!__any(nearTarget)) {
 #pragma unroll
                         for (uint32_t gq = 0; gq < kSpecRound / 4; gq++) {
-                            uint32_t const Q = (uint32_t)(Qbase + cur);
-                            uint32_t tHi, tLo;
-                            peek64(winL, Q, tHi, tLo);
-                            // (the first code of a group is looked up in what the previous group left of its 64 bits -- at least 20 --
-                            // while the window words of this group are on their way)
-                            uint32_t const c0 = cells[rem >> shift];
-                            uint32_t const l0 = c0 >> 8;
-                            uint32_t const c1 = cells[shl_hi(tHi, tLo, l0) >> shift];
-                            uint32_t const l1 = l0 + (c1 >> 8);
-                            uint32_t const c2 = cells[shl_hi(tHi, tLo, l1) >> shift];
-                            uint32_t const l2 = l1 + (c2 >> 8);
-                            uint32_t const c3 = cells[shl_hi(tHi, tLo, l2) >> shift];
-                            uint32_t const l3 = l2 + (c3 >> 8);
-                            soL[gq] = (c0 & 0xFF) | ((c1 & 0xFF) << 8) | ((c2 & 0xFF) << 16) | (c3 << 24);
-                            // code boundaries of the four symbols: cur, cur - l0, cur - l1, cur - l2
-                            int const cb0 = cur, cb1 = cur - (int)l0, cb2 = cur - (int)l1, cb3 = cur - (int)l2;
-                            if (__any(cur + (int)kSpecZone > Bj)) {
-                                // own zone: mark the boundaries (a boundary outside the zone ORs nothing into the map's first word)
-                                uint32_t const h0 = (uint32_t)(Bj - cb0), h1 = (uint32_t)(Bj - cb1), h2 = (uint32_t)(Bj - cb2), h3 = (uint32_t)(Bj - cb3);
-                                atomicOr(hbm + (h0 < kSpecZone ? h0 >> 5 : 0u), h0 < kSpecZone ? 1u << (h0 & 31) : 0u);
-                                atomicOr(hbm + (h1 < kSpecZone ? h1 >> 5 : 0u), h1 < kSpecZone ? 1u << (h1 & 31) : 0u);
-                                atomicOr(hbm + (h2 < kSpecZone ? h2 >> 5 : 0u), h2 < kSpecZone ? 1u << (h2 & 31) : 0u);
-                                atomicOr(hbm + (h3 < kSpecZone ? h3 >> 5 : 0u), h3 < kSpecZone ? 1u << (h3 & 31) : 0u);
+                            uint32_t tHi[2], tLo[2], c0[2], c1[2], c2[2], c3[2], l0[2], l1[2], l2[2], l3[2];
+#pragma unroll
+                            for (int c = 0; c < 2; c++) peek64(winL[c], (uint32_t)(Qbase[c] + cur[c]), tHi[c], tLo[c]);
+#pragma unroll
+                            for (int c = 0; c < 2; c++) c0[c] = cells[rem[c] >> shift];
+#pragma unroll
+                            for (int c = 0; c < 2; c++) { l0[c] = c0[c] >> 8; c1[c] = cells[shl_hi(tHi[c], tLo[c], l0[c]) >> shift]; }
+#pragma unroll
+                            for (int c = 0; c < 2; c++) { l1[c] = l0[c] + (c1[c] >> 8); c2[c] = cells[shl_hi(tHi[c], tLo[c], l1[c]) >> shift]; }
+#pragma unroll
+                            for (int c = 0; c < 2; c++) { l2[c] = l1[c] + (c2[c] >> 8); c3[c] = cells[shl_hi(tHi[c], tLo[c], l2[c]) >> shift]; }
+#pragma unroll
+                            for (int c = 0; c < 2; c++) {
+                                l3[c] = l2[c] + (c3[c] >> 8);
+                                soL[c][gq] = (c0[c] & 0xFF) | ((c1[c] & 0xFF) << 8) | ((c2[c] & 0xFF) << 16) | (c3[c] << 24);
+                                uint32_t const adv = act[c] ? l3[c] : 0u;
+                                cur[c] -= (int)adv;
+                                rem[c] = shl_hi(tHi[c], tLo[c], adv);
                             }
-                            if (__any(cur - 48 <= Bt)) {
-                                // the zone of the part ahead: is one of the boundaries marked there?  (the end of the stream: is one of them bit 0?)
-                                const uint32_t* const tmap = maps + (k + 4 * (t < 4 ? t : 0u)) * kMapDw;
-                                uint32_t const b0 = (uint32_t)(Bt - cb0), b1 = (uint32_t)(Bt - cb1), b2 = (uint32_t)(Bt - cb2), b3 = (uint32_t)(Bt - cb3);
-                                uint32_t const w0 = tmap[b0 < kSpecZone ? b0 >> 5 : 0u], w1 = tmap[b1 < kSpecZone ? b1 >> 5 : 0u],
-                                               w2 = tmap[b2 < kSpecZone ? b2 >> 5 : 0u], w3 = tmap[b3 < kSpecZone ? b3 >> 5 : 0u];
-                                bool const last = t == 4;
-                                bool const x0 = last ? cb0 == 0 : (b0 < kSpecZone && ((w0 >> (b0 & 31)) & 1u));
-                                bool const x1 = last ? cb1 == 0 : (b1 < kSpecZone && ((w1 >> (b1 & 31)) & 1u));
-                                bool const x2 = last ? cb2 == 0 : (b2 < kSpecZone && ((w2 >> (b2 & 31)) & 1u));
-                                bool const x3 = last ? cb3 == 0 : (b3 < kSpecZone && ((w3 >> (b3 & 31)) & 1u));
-                                if ((x0 | x1 | x2 | x3) && !met && !failed) {
-                                    met = true;
-                                    upTo = nDec + (x0 ? 0u : x1 ? 1u : x2 ? 2u : 3u);
-                                    meetBit = x0 ? b0 : x1 ? b1 : x2 ? b2 : b3;
+                        }
+#pragma unroll
+                        for (int c = 0; c < 2; c++) nDec[c] += act[c] ? kSpecRound : 0u;
+                    } else
+#pragma unroll
+                    for (uint32_t gq = 0; gq < kSpecRound / 4; gq++) {
+                        uint32_t tHi[2], tLo[2], c0[2], c1[2], c2[2], c3[2], l0[2], l1[2], l2[2], l3[2];
+                        // the two parts' lookups alternate: each waits for its own previous one while the other's is in flight
+#pragma unroll
+                        for (int c = 0; c < 2; c++) peek64(winL[c], (uint32_t)(Qbase[c] + cur[c]), tHi[c], tLo[c]);
+                        // (the first code of a group is looked up in what the previous group left of its 64 bits -- at least 20 --
+                        // while the window words of this group are on their way)
+#pragma unroll
+                        for (int c = 0; c < 2; c++) c0[c] = cells[rem[c] >> shift];
+#pragma unroll
+                        for (int c = 0; c < 2; c++) { l0[c] = c0[c] >> 8; c1[c] = cells[shl_hi(tHi[c], tLo[c], l0[c]) >> shift]; }
+#pragma unroll
+                        for (int c = 0; c < 2; c++) { l1[c] = l0[c] + (c1[c] >> 8); c2[c] = cells[shl_hi(tHi[c], tLo[c], l1[c]) >> shift]; }
+#pragma unroll
+                        for (int c = 0; c < 2; c++) { l2[c] = l1[c] + (c2[c] >> 8); c3[c] = cells[shl_hi(tHi[c], tLo[c], l2[c]) >> shift]; }
+#pragma unroll
+                        for (int c = 0; c < 2; c++) {
+                            l3[c] = l2[c] + (c3[c] >> 8);
+                            soL[c][gq] = (c0[c] & 0xFF) | ((c1[c] & 0xFF) << 8) | ((c2[c] & 0xFF) << 16) | (c3[c] << 24);
+                        }
+#pragma unroll
+                        for (int c = 0; c < 2; c++) {
+                            // code boundaries of the four symbols
+                            int const cb0 = cur[c], cb1 = cur[c] - (int)l0[c], cb2 = cur[c] - (int)l1[c], cb3 = cur[c] - (int)l2[c];
+                            bool const open0 = act[c] && !met[c] && !failed[c];
+                            if (__any(open0 && cur[c] - 48 <= Bt[c])) {
+                                // in the part ahead: is one of the boundaries where that part noted to be?  (the end of the stream: is
+                                // one of them bit 0?)
+                                bool const last = t[c] == kSpecParts;
+                                ckv[c] = (!last && q[c] < 16) ? (uint32_t)ckAll[16 * (k + 4 * (last ? 0u : t[c])) + (q[c] < 16 ? q[c] : 0u)] : 0xFFFFu;
+                                bool const valid = last || ckv[c] < 0xFFFEu;      // (0xFFFF: not noted yet, or no notes left)
+                                int const goal = last ? 0 : Bt[c] - (int)ckv[c];
+                                bool const x0 = valid && cb0 == goal, x1 = valid && cb1 == goal, x2 = valid && cb2 == goal, x3 = valid && cb3 == goal;
+                                if ((x0 | x1 | x2 | x3) && open0) {
+                                    met[c] = true;
+                                    upTo[c] = nDec[c] + (x0 ? 0u : x1 ? 1u : x2 ? 2u : 3u);
+                                    hdT[c] = kSpecRound * q[c];
                                 }
                             }
-                            nDec += 4;
-                            cur -= (int)l3;
-                            rem = shl_hi(tHi, tLo, l3);
-                            {
-                                bool const open = !met && !failed;
-                                bool const atEnd = open && t == 4;
-                                if (atEnd && cur == 0) { met = true; upTo = nDec; }
-                                if (atEnd && cur < 0) failed = true;
-                                bool const carryOn = open && t < 4 && cur <= Bt - (int)kSpecZone;      // crossed the zone without meeting: on through that part
-                                t += carryOn ? 1u : 0u;
-                                Bt = boundary(t);
+                            if (act[c]) {
+                                nDec[c] += 4;
+                                cur[c] -= (int)l3[c];
+                                rem[c] = shl_hi(tHi[c], tLo[c], l3[c]);
+                                bool const open = !met[c] && !failed[c];
+                                bool const atEnd = open && t[c] == kSpecParts;
+                                if (atEnd && cur[c] == 0) { met[c] = true; upTo[c] = nDec[c]; }
+                                if (atEnd && cur[c] < 0) failed[c] = true;
+                                if (open && t[c] < kSpecParts) {
+                                    // past the note in hand: on to the next one; past the last one without a hit: on through that part
+                                    if (ckv[c] < 0xFFFEu && Bt[c] - cur[c] > (int)ckv[c]) { q[c]++; ckv[c] = 0xFFFFu; }
+                                    if (q[c] >= 16) { t[c]++; Bt[c] = boundary(t[c]); q[c] = 0; ckv[c] = 0xFFFFu; }
+                                }
                             }
                         }
                     }
                 }
                 lds_sync();
-#ifdef ZG_STAMPS
-                zC += __builtin_readcyclecounter() - zc;
-#endif
             }
-#ifdef ZG_STAMPS
-            uint64_t const z1 = __builtin_readcyclecounter();
-#endif
-            // ---- what every lane found: {target part, symbols before the meeting point, symbols the target decoded before it, ok}
-            uint32_t headOfTarget = 0;
-            if (met && t < 4) {
-                const uint32_t* const tmap = maps + (k + 4 * t) * kMapDw;
-                for (uint32_t w = 0; w <= (meetBit >> 5); w++) {
-                    uint32_t const word = tmap[w];
-                    headOfTarget += __builtin_popcount(w < (meetBit >> 5) ? word : word & ((1u << (meetBit & 31)) - 1u));
-                }
-            }
+            // ---- what every part found: {target part, symbols before the meeting point, symbols the target decoded before it, ok}
             lds_sync();
-            uint4* const recs = (uint4*)outStage;       // [16 lanes], the output stages are free now
-            recs[sl] = make_uint4(t, upTo, headOfTarget, (met && !failed) ? 1u : 0u);
+            uint4* const recs = (uint4*)outAll;       // [32 parts], the output stages are free now
+#pragma unroll
+            for (int c = 0; c < 2; c++) recs[sl + 16 * c] = make_uint4(t[c], upTo[c], hdT[c], (met[c] && !failed[c]) ? 1u : 0u);
             lds_sync();
             // walk the stream's parts along the true path: part 0, then the part it met, and so on to the end
-            uint32_t val0 = 0, val1 = 0, val2 = 0, val3 = 0, hd0 = 0, hd1 = 0, hd2 = 0, hd3 = 0;
+            uint32_t val[2] = {0, 0}, hd[2] = {0, 0}, dOff[2] = {0, 0};
             bool chainOk = true;
+            uint32_t acc = 0;
             {
                 uint32_t part = 0, head = 0;
 #pragma unroll
-                for (int step = 0; step < 4; step++) {
-                    if (part < 4) {
+                for (int step = 0; step < (int)kSpecParts; step++) {
+                    if (part < kSpecParts) {
                         uint4 const rc = recs[k + 4 * part];
                         uint32_t const vv = rc.y - head;
                         if (!rc.w || rc.y < head || rc.y > laneCap) chainOk = false;
-                        if (part == 0) { val0 = vv; hd0 = head; } else if (part == 1) { val1 = vv; hd1 = head; } else if (part == 2) { val2 = vv; hd2 = head; } else { val3 = vv; hd3 = head; }
+#pragma unroll
+                        for (int c = 0; c < 2; c++) {
+                            uint32_t const P = j + 4 * c;
+                            if (P == part) { val[c] = vv; hd[c] = head; dOff[c] = acc; }
+                            if (P > part && P < rc.x) { val[c] = 0; hd[c] = 0; dOff[c] = acc + vv; }      // a part the path skips
+                        }
+                        acc += vv;
                         head = rc.z;
                         part = rc.x;
                     }
                 }
-                if (part != 4) chainOk = false;
+                if (part != kSpecParts) chainOk = false;
             }
-            bool const lbad = !chainOk || val0 + val1 + val2 + val3 != myCnt;
+            bool const lbad = !chainOk || acc != myCnt;
             specDone = ((__ballot(lbad) >> lead) & 0xFFFFu) == 0;
 #ifdef ZG_STAMPS
             if (p.dbg) {
-                uint64_t* const q = p.dbg + 16 * (size_t)p.nBlocks + 16 * (size_t)b;
-                atomicOr((unsigned long long*)&q[12], (unsigned long long)(64u | (failed ? 1u : 0u) | (!chainOk ? 2u : 0u) | (lbad ? 4u : 0u) | (t != j + 1 ? 8u : 0u)));
-                if (sl == 0) { q[1] = zA; q[2] = zB; q[3] = zC; q[4] = z1 - z0; }
+                uint64_t* const qd = p.dbg + 16 * (size_t)p.nBlocks + 16 * (size_t)b;
+                atomicOr((unsigned long long*)&qd[12], (unsigned long long)(64u | ((failed[0] || failed[1]) ? 1u : 0u) | (!chainOk ? 2u : 0u) | (lbad ? 4u : 0u) | ((t[0] != j + 1 || t[1] != j + 5) ? 8u : 0u)));
             }
-#endif
-#ifdef ZG_STAMPS
-            uint64_t const z2 = __builtin_readcyclecounter();
 #endif
             if (specDone) {
-                // ---- leave the part table for the pack kernel: {first byte, end} in the literal buffer and the address
-                // that byte 0 of the buffer would have in the part's scratch region
-                uint32_t const valid = j == 0 ? val0 : j == 1 ? val1 : j == 2 ? val2 : val3;
-                uint32_t const myHead = j == 0 ? hd0 : j == 1 ? hd1 : j == 2 ? hd2 : hd3;
-                uint32_t const dOff = j == 0 ? 0u : j == 1 ? val0 : j == 2 ? val0 + val1 : val0 + val1 + val2;
-                uint32_t const dStart = k * g.seg + dOff;
-                uintptr_t const delta = (uintptr_t)(tmpL + myHead) - dStart;
-                p.packTab[(size_t)job * kPackTabEntries + 4 * k + j] = make_uint4(dStart, dStart + valid, (uint32_t)delta, (uint32_t)((uint64_t)delta >> 32));
+                // ---- leave the part table for the pack kernel, in output order: {first byte, end} in the literal buffer and the
+                // address that byte 0 of the buffer would have in the part's scratch region
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    uint32_t const P = j + 4 * c;
+                    uint32_t const dStart = k * g.seg + dOff[c];
+                    uintptr_t const delta = (uintptr_t)(tmpL[c] + hd[c]) - dStart;
+                    p.packTab[(size_t)job * kPackTabEntries + kSpecParts * k + P] = make_uint4(dStart, dStart + val[c], (uint32_t)delta, (uint32_t)((uint64_t)delta >> 32));
+                }
             }
-#ifdef ZG_STAMPS
-            if (p.dbg && sl == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); uint64_t* const q = p.dbg + 16 * (size_t)p.nBlocks + 16 * (size_t)b; q[5] = z2 - z1; q[6] = __builtin_readcyclecounter() - z2; }
-#endif
         }
     }
     uint32_t const maxCntSerial = specDone ? 0u : maxCnt;
@@ -1008,14 +1047,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
     if (sl == 0) {
         uint32_t const mine = (uint32_t)((anyBad >> lead) & ((1u << kHufLanes) - 1));
         p.state[b].litErr = err ? err : (mine ? (uint32_t)E_corruption : 0u);
-        p.packTab[(size_t)job * kPackTabEntries + 16] = make_uint4(specDone ? 1u : 0u, 0, 0, 0);     // does the pack kernel have work for this block?
+        p.packTab[(size_t)job * kPackTabEntries + 4 * kSpecParts] = make_uint4(specDone ? 1u : 0u, 0, 0, 0);     // does the pack kernel have work for this block?
 #ifdef ZG_STAMPS
         if (p.dbg) { uint64_t* const q = p.dbg + 16 * (size_t)p.nBlocks + 16 * (size_t)b; q[0] = y1 - y0; if (!specDone) { q[1] = yA; q[2] = yB; q[3] = yC; q[4] = yD; q[5] = yN; q[6] = yS; } q[7] = __builtin_readcyclecounter() - y0; q[8] = blk.litSize; q[9] = yp - y0; q[10] = yf - yp; q[11] = 0; }
 #endif
     }
 }
 
-// Literals of a block that were decoded in 16 parts (split decode above): copy every part's valid bytes from its
+// Literals of a block that were decoded in 32 parts (split decode above): copy every part's valid bytes from its
 // scratch region to its place in the literal buffer.  One workgroup per block; the destination is dense, so the
 // workgroup walks it in 16-byte units (all loads of a thread first, then its stores); a unit that lies in one part is
 // one 16-byte copy, a unit that spans parts goes byte by byte.
@@ -1024,11 +1063,11 @@ constexpr int kPackThreads = 256;
 constexpr int kPackUnits = 12;      // units per thread and pass: 256 x 12 x 16 bytes = 48 KB, a whole block's literals in most cases
 __global__ __launch_bounds__(kPackThreads) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_pack_literals(BatchParams p)
 {
-    __shared__ uint4 parts[16];
+    __shared__ uint4 parts[32];
     uint32_t const job = blockIdx.x, tid = threadIdx.x;
     const uint4* const tab = p.packTab + (size_t)job * kPackTabEntries;
-    if (tab[16].x == 0) return;
-    if (tid < 16) parts[tid] = tab[tid];
+    if (tab[32].x == 0) return;
+    if (tid < 32) parts[tid] = tab[tid];
     __syncthreads();
     DevBlock const blk = p.blocks[p.litJobs[job]];
     uint8_t* const out = p.litBuf + blk.litBufOff;
@@ -1037,8 +1076,8 @@ __global__ __launch_bounds__(kPackThreads) __attribute__((amdgpu_waves_per_eu(4,
     auto part_of = [&](uint32_t d) -> uint32_t {
         uint32_t q = 0;
 #pragma unroll
-        for (int stepq = 8; stepq >= 1; stepq >>= 1) q += parts[q + stepq - 1].y <= d ? (uint32_t)stepq : 0u;
-        return q < 15 ? q : 15u;
+        for (int stepq = 16; stepq >= 1; stepq >>= 1) q += parts[q + stepq - 1].y <= d ? (uint32_t)stepq : 0u;
+        return q < 31 ? q : 31u;
     };
     for (uint32_t first = 0; first < nUnits; first += kPackThreads * kPackUnits) {
         uint4 x[kPackUnits];
@@ -1064,7 +1103,7 @@ __global__ __launch_bounds__(kPackThreads) __attribute__((amdgpu_waves_per_eu(4,
     }
     // units that span parts (or the end of the buffer) each hold the end of some part: one thread per part gathers
     // the bytes of that unit, all loads in flight together
-    if (tid < 16) {
+    if (tid < 32) {
         uint32_t const e = parts[tid].y;
         if (e & 15u) {
             uint32_t const d = e & ~15u;

@@ -505,7 +505,7 @@ extern "C" zstdgpu_batch* zstdgpu_batch_create(zstdgpu_ctx* ctx, const void* hos
             if (d.litType >= SET_COMPRESSED) {
                 d.litBufOff = litOff;
                 litOff += (d.litSize + 15) & ~15ull;
-                if (!d.singleStream) { d.litTmpOff = tmpOff; tmpOff += 16ull * litTmpLane(d.litSize); }
+                if (!d.singleStream) { d.litTmpOff = tmpOff; tmpOff += litTmpBytes(d.litSize); }
                 B->hLitJobs.push_back(b);
             }
             if (d.hostSeqErr) { dead = true; continue; }
@@ -525,7 +525,7 @@ extern "C" zstdgpu_batch* zstdgpu_batch_create(zstdgpu_ctx* ctx, const void* hos
     bool ok = dalloc(B->dBlocks, nBlocks, B->scratchBytes) && dalloc(B->dState, nBlocks, B->scratchBytes) &&
               dalloc(B->dFrames, nFrames, B->scratchBytes) && dalloc(B->dStatus, nFrames, B->scratchBytes) &&
               balloc(ctx, B->dLitBuf, B->litBytes, B->litBufBytes, B->scratchBytes) && balloc(ctx, B->dLitTmp, tmpOff + 64, B->litTmpBytes, B->scratchBytes) && balloc(ctx, B->dSeqBuf, seqOff * 4 + 4, B->seqBufBytes, B->scratchBytes) &&
-              dalloc(B->dLitJobs, B->hLitJobs.size(), B->scratchBytes) && dalloc(B->dPackTab, B->hLitJobs.size() * 17 + 1, B->scratchBytes) && dalloc(B->dSeqJobs, B->hSeqJobs.size(), B->scratchBytes);
+              dalloc(B->dLitJobs, B->hLitJobs.size(), B->scratchBytes) && dalloc(B->dPackTab, B->hLitJobs.size() * 33 + 1, B->scratchBytes) && dalloc(B->dSeqJobs, B->hSeqJobs.size(), B->scratchBytes);
     auto up = [&](void* d, const void* h, size_t n) { return n == 0 || hipMemcpy(d, h, n, hipMemcpyHostToDevice) == hipSuccess; };
     ok = ok && up(B->dBlocks, B->hBlocks.data(), nBlocks * sizeof(DevBlock)) && up(B->dFrames, B->hFrames.data(), nFrames * sizeof(DevFrame)) &&
          up(B->dLitJobs, B->hLitJobs.data(), B->hLitJobs.size() * 4) && up(B->dSeqJobs, B->hSeqJobs.data(), B->hSeqJobs.size() * 4);
@@ -585,7 +585,7 @@ extern "C" zstdgpu_batch* zstdgpu_batch_create_on_device(zstdgpu_ctx* ctx, const
         size_t const nLit = (size_t)totals[4], nSeq = (size_t)totals[5];
         B->litBytes = litOff + 64; B->nSeqTotal = seqOff;
         ok = balloc(ctx, B->dLitBuf, B->litBytes, B->litBufBytes, B->scratchBytes) && balloc(ctx, B->dLitTmp, tmpOff + 64, B->litTmpBytes, B->scratchBytes) &&
-             balloc(ctx, B->dSeqBuf, seqOff * 4 + 4, B->seqBufBytes, B->scratchBytes) && dalloc(B->dPackTab, nLit * 17 + 1, B->scratchBytes);
+             balloc(ctx, B->dSeqBuf, seqOff * 4 + 4, B->seqBufBytes, B->scratchBytes) && dalloc(B->dPackTab, nLit * 33 + 1, B->scratchBytes);
         B->nFrames = nFrames; B->nBlocks = nBlocks; B->nLitJobs = (uint32_t)nLit; B->nSeqJobs = (uint32_t)nSeq;
         B->srcBytes = totals[6];
         B->mirrored = false;

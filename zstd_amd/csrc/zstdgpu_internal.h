@@ -17,9 +17,10 @@ enum : uint8_t { BT_RAW = 0, BT_RLE = 1, BT_COMPRESSED = 2, BT_STOP = 3 };   // 
 enum : uint8_t { SET_BASIC = 0, SET_RLE = 1, SET_COMPRESSED = 2, SET_REPEAT = 3 };  // symbolEncodingType_e (zstd_internal.pas:112-118)
 
 constexpr uint32_t kBlockSizeMax = 1u << 17;
-// bytes per lane region of the split literal decode: a quarter stream regenerates about litSize/16 bytes; twice that
-// plus slack is allowed before the block falls back to whole-stream decoding
-constexpr uint32_t litTmpLane(uint32_t litSize) { return ((litSize + 3) / 4 / 2 + 256 + 31) & ~31u; }
+// bytes per scratch region of the split literal decode (32 per block: every stream in 8 parts): a part regenerates
+// about litSize/32 bytes; twice that plus slack is allowed before the block falls back to whole-stream decoding
+constexpr uint32_t litTmpPart(uint32_t litSize) { return ((litSize + 3) / 4 / 4 + 256 + 31) & ~31u; }
+constexpr uint64_t litTmpBytes(uint32_t litSize) { return 32ull * litTmpPart(litSize); }
 constexpr uint32_t kSymbolicRep = 0x80000000u;   // sequence offset / rep value that refers to the block's incoming rep stack
 
 // Per-block descriptor consumed by the kernels (built on the host).
@@ -27,7 +28,7 @@ struct DevBlock {
     uint64_t srcOff;       // block payload in the source buffer
     uint64_t litBufOff;    // decoded literals go here (litType compressed/repeat)
     uint64_t seqBufOff;    // first sequence slot of this block
-    uint64_t litTmpOff;    // 4-stream Huffman literals: 16 regions of litTmpLane(litSize) bytes for the split decode
+    uint64_t litTmpOff;    // 4-stream Huffman literals: 32 regions of litTmpPart(litSize) bytes for the split decode
     uint32_t cSize;
     uint32_t origSize;     // raw/RLE regenerated size
     uint32_t frameIdx;
