@@ -707,6 +707,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
             static_assert(4096 + 1024 + 32 * 4 * kSpecWinDw + 32 * kSpecRound <= kHufJobBytes, "split decode fits in the job's LDS");
             auto boundary = [&](uint32_t t) -> int { return T - (int)(((uint64_t)t * (uint32_t)T) >> 3); };     // first bit of part t (0 for t = 8)
             uint32_t const laneCap = litTmpPart(blk.litSize);
+            uint8_t* const dump = p.litTmp + blk.litTmpOff + 32 * (size_t)laneCap;
             // per part of this lane (c = 0, 1; constant indices once unrolled)
             int cur[2], Bs[2], Bt[2];
             uint32_t t[2], nDec[2], upTo[2], hdT[2], q[2], ckv[2], rem[2];
@@ -728,8 +729,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
                 *(uint4*)ckL[c] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);      // "not noted yet": matches nothing
                 *(uint4*)(ckL[c] + 8) = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
             }
-            bool havePv = false;
+            bool hasPv[2] = {false, false};
+            int lastCur[2] = {cur[0], cur[1]};
+            uint32_t lastUse[2] = {tableLog * kSpecRound, tableLog * kSpecRound};      // bits the previous round consumed
+#ifdef ZG_STAMPS
+            uint64_t zA = 0, zB = 0, zC = 0, zR = 0, zF = 0; uint64_t const z0 = __builtin_readcyclecounter();
+#endif
             for (uint32_t r = 0;; r++) {
+#ifdef ZG_STAMPS
+                uint64_t const za = __builtin_readcyclecounter();
+#endif
                 bool act[2];
 #pragma unroll
                 for (int c = 0; c < 2; c++) act[c] = !met[c] && !failed[c];
@@ -751,7 +760,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
                 bool low = false;
 #pragma unroll
                 for (int c = 0; c < 2; c++) {
-                    uintptr_t const wbCand = havePv ? pwb[c] : wbL[c];
+                    lastUse[c] = r ? (uint32_t)(lastCur[c] - cur[c]) : lastUse[c]; lastCur[c] = cur[c];
+                    uintptr_t const wbCand = hasPv[c] ? pwb[c] : wbL[c];
                     low = low || (act[c] && (r == 0 || (int)(8 * (int64_t)((uintptr_t)myStart - wbCand)) + cur[c] < (int)(tableLog * kSpecRound + 96)));
                 }
                 bool const stage = anyActive && ((__ballot(low) >> lead) & 0xFFFFu) != 0;
@@ -765,16 +775,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
                         for (int u = 0; u < 6; u++) v[c][u] = ld_unit_any(wbS[c] + 16 * u, floorAddr);
                     }
                 }
-                // the previous round's bytes go to the parts' scratch regions
+                // (every lane stores, a part with nothing to flush into the spare bytes behind the block's regions: a fixed
+                // number of stores lets the wait for the window loads issued ahead of them be counted)
+                auto flush_prev = [&]() {
 #pragma unroll
-                for (int c = 0; c < 2; c++) {
-                    if (prevActive[c]) {
+                    for (int c = 0; c < 2; c++) {
                         uint4 const x0 = *(const uint4*)soL[c], x1v = *(const uint4*)(soL[c] + 4);
-                        __builtin_memcpy(tmpL[c] + kSpecRound * (r - 1), &x0, 16);
-                        __builtin_memcpy(tmpL[c] + kSpecRound * (r - 1) + 16, &x1v, 16);
+                        uint8_t* const d = prevActive[c] ? tmpL[c] + kSpecRound * (r - 1) : dump;
+                        __builtin_memcpy(d, &x0, 16);
+                        __builtin_memcpy(d + 16, &x1v, 16);
                     }
-                }
-                if (!anyActive) break;
+                };
+                if (!anyActive) { flush_prev(); break; }
+#ifdef ZG_STAMPS
+                uint64_t const zb = __builtin_readcyclecounter();
+#endif
                 lds_sync();
 #pragma unroll
                 for (int c = 0; c < 2; c++) {
@@ -782,20 +797,29 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
                         wbL[c] = wbS[c];
 #pragma unroll
                         for (int u = 0; u < 6; u++) *(uint4*)(winL[c] + 4 * u) = v[c][u];
-                    } else if (havePv) {
+                    } else if (hasPv[c]) {
                         wbL[c] = pwb[c];
 #pragma unroll
                         for (int u = 0; u < 6; u++) *(uint4*)(winL[c] + 4 * u) = pv[c][u];
                     }
+                    hasPv[c] = false;
                 }
                 lds_sync();
 #pragma unroll
-                for (int c = 0; c < 2; c++) {       // the windows the next round will start from
-                    pwb[c] = window_base(cur[c]);
+                for (int c = 0; c < 2; c++) {
+                    // The window the next round will start from -- when the one in place would not feed it: what is left now,
+                    // less what this round will take (about what the last one took), against the most a round can take.
+                    int const left = (int)(8 * (int64_t)((uintptr_t)myStart - wbL[c])) + cur[c];
+                    if (act[c] && left - (int)(lastUse[c] + lastUse[c] / 4 + 16) < (int)(tableLog * kSpecRound + 96)) {
+                        pwb[c] = window_base(cur[c]);
 #pragma unroll
-                    for (int u = 0; u < 6; u++) pv[c][u] = ld_unit_any(pwb[c] + 16 * u, floorAddr);
+                        for (int u = 0; u < 6; u++) pv[c][u] = ld_unit_any(pwb[c] + 16 * u, floorAddr);
+                        hasPv[c] = true;
+                    }
                 }
-                havePv = true;
+                // The previous round's bytes go to the parts' scratch regions: behind the window requests, which must not wait
+                // for these stores to be acknowledged.
+                flush_prev();
 #pragma unroll
                 for (int c = 0; c < 2; c++) {
                     prevActive[c] = false;
@@ -804,6 +828,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
                         else prevActive[c] = true;
                     }
                 }
+#ifdef ZG_STAMPS
+                uint64_t const zc = __builtin_readcyclecounter();
+                zA += zb - za; zB += zc - zb; zR += 1;
+#endif
                 if (act[0] || act[1]) {
                     int Qbase[2];
 #pragma unroll
@@ -818,6 +846,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
                     bool nearTarget = false;
 #pragma unroll
                     for (int c = 0; c < 2; c++) nearTarget = nearTarget || (act[c] && cur[c] - (int)(tableLog * kSpecRound + 64) <= Bt[c]);
+#ifdef ZG_STAMPS
+                    zF += __any(nearTarget) ? 0 : 1;
+#endif
                     if (!__any(nearTarget)) {
 #pragma unroll
                         for (uint32_t gq = 0; gq < kSpecRound / 4; gq++) {
@@ -902,7 +933,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
                     }
                 }
                 lds_sync();
+#ifdef ZG_STAMPS
+                zC += __builtin_readcyclecounter() - zc;
+#endif
             }
+#ifdef ZG_STAMPS
+            if (p.dbg && sl == 0) { uint64_t* const qd = p.dbg + 16 * (size_t)p.nBlocks + 16 * (size_t)b; qd[1] = zA; qd[2] = zB; qd[3] = zC; qd[4] = __builtin_readcyclecounter() - z0; qd[5] = zR; qd[6] = zF; }
+#endif
             // ---- what every part found: {target part, symbols before the meeting point, symbols the target decoded before it, ok}
             lds_sync();
             uint4* const recs = (uint4*)outAll;       // [32 parts], the output stages are free now

@@ -20,7 +20,7 @@ constexpr uint32_t kBlockSizeMax = 1u << 17;
 // bytes per scratch region of the split literal decode (32 per block: every stream in 8 parts): a part regenerates
 // about litSize/32 bytes; twice that plus slack is allowed before the block falls back to whole-stream decoding
 constexpr uint32_t litTmpPart(uint32_t litSize) { return ((litSize + 3) / 4 / 4 + 256 + 31) & ~31u; }
-constexpr uint64_t litTmpBytes(uint32_t litSize) { return 32ull * litTmpPart(litSize); }
+constexpr uint64_t litTmpBytes(uint32_t litSize) { return 32ull * litTmpPart(litSize) + 64; }     // + a place for stores that must go nowhere
 constexpr uint32_t kSymbolicRep = 0x80000000u;   // sequence offset / rep value that refers to the block's incoming rep stack
 
 // Per-block descriptor consumed by the kernels (built on the host).
