@@ -122,6 +122,28 @@ size_t zstdgpu_initDStream_usingDDict(zstdgpu_dstream* zds, const zstdgpu_ddict*
 size_t zstdgpu_resetDStream(zstdgpu_dstream* zds);                                 /* ZSTD_resetDStream :1630 */
 size_t zstdgpu_decompressStream(zstdgpu_dstream* zds, zstdgpu_outBuffer* output, zstdgpu_inBuffer* input);   /* :1978 */
 
+/* ---- decoder parameters (ZSTD_dParameter common/zstd.pas:289-309, :580-582; decompress/zstd_decompressf.pas:1641-1826)
+ * As in the reference, where a stream is the decoding context itself, parameters and the referenced dictionary
+ * belong to the context: they apply to zstdgpu_decompressDCtx, to batches built from frame entries
+ * (zstdgpu_batch_create_from_frames / _on_device) and to every stream opened on the context.  They can only be
+ * changed while no stream of the context is inside a frame (stage_wrong otherwise).
+ *   windowLogMax        streams refuse frames whose window exceeds 1 << value (default 27; 0 selects the default)
+ *   format              0 = ZSTD_f_zstd1, 1 = ZSTD_f_zstd1_magicless (frames start at the descriptor byte)
+ *   stableOutBuffer     1: the caller passes the same, large enough, output buffer to every call of a frame
+ *   forceIgnoreChecksum 1: the checksum trailer is skipped instead of compared */
+typedef enum {
+    ZSTDGPU_d_windowLogMax = 100, ZSTDGPU_d_format = 1000, ZSTDGPU_d_stableOutBuffer = 1001, ZSTDGPU_d_forceIgnoreChecksum = 1002
+} zstdgpu_dParameter;
+typedef enum {
+    ZSTDGPU_reset_session_only = 1, ZSTDGPU_reset_parameters = 2, ZSTDGPU_reset_session_and_parameters = 3
+} zstdgpu_ResetDirective;                                                           /* ZSTD_ResetDirective zstd.pas:275-279 */
+typedef struct { size_t error; int lowerBound; int upperBound; } zstdgpu_bounds;   /* ZSTD_bounds zstd.pas:270-274 */
+zstdgpu_bounds zstdgpu_dParam_getBounds(zstdgpu_dParameter param);                               /* :1680 */
+size_t zstdgpu_DCtx_setParameter(zstdgpu_ctx* ctx, zstdgpu_dParameter param, int value);        /* :1763 */
+size_t zstdgpu_DCtx_getParameter(zstdgpu_ctx* ctx, zstdgpu_dParameter param, int* value);       /* :1735 */
+size_t zstdgpu_DCtx_refDDict(zstdgpu_ctx* ctx, const zstdgpu_ddict* ddict);                     /* :1641; used by zstdgpu_decompressDCtx (ZSTD_getDDict :951) */
+size_t zstdgpu_DCtx_reset(zstdgpu_ctx* ctx, zstdgpu_ResetDirective reset);                      /* :1809 */
+
 /* One source frame of a batch: where it is and where its output goes. */
 typedef struct {
     uint64_t srcOff, srcSize, dstOff, dstCapacity;

@@ -23,6 +23,7 @@ def lib():
         sz, vp, u64, u32 = ctypes.c_size_t, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32
         L.oracle_decompress.argtypes = [vp, sz, vp, sz]; L.oracle_decompress.restype = sz
         L.oracle_decompress_usingDict.argtypes = [vp, sz, vp, sz, vp, sz]; L.oracle_decompress_usingDict.restype = sz
+        L.oracle_decompress_advanced.argtypes = [vp, sz, vp, sz, vp, sz, ctypes.c_uint, ctypes.c_uint]; L.oracle_decompress_advanced.restype = sz
         L.oracle_decompress_traced.argtypes = [vp, sz, vp, sz, vp, sz, vp]; L.oracle_decompress_traced.restype = sz
         L.oracle_isError.argtypes = [sz]; L.oracle_isError.restype = ctypes.c_uint
         L.oracle_getErrorCode.argtypes = [sz]; L.oracle_getErrorCode.restype = ctypes.c_uint
@@ -40,12 +41,15 @@ def lib():
     return _lib
 
 
-def decompress(frame: bytes, capacity: int, dictionary: bytes = None):
+def decompress(frame: bytes, capacity: int, dictionary: bytes = None, magicless: bool = False, ignore_checksum: bool = False):
     """Returns (bytes, 0) on success or (None, zstd error code)."""
     L = lib()
     out = ctypes.create_string_buffer(max(capacity, 1))
     d = dictionary or b""
-    r = L.oracle_decompress_usingDict(out, capacity, frame, len(frame), d if d else None, len(d))
+    if magicless or ignore_checksum:
+        r = L.oracle_decompress_advanced(out, capacity, frame, len(frame), d if d else None, len(d), int(magicless), int(ignore_checksum))
+    else:
+        r = L.oracle_decompress_usingDict(out, capacity, frame, len(frame), d if d else None, len(d))
     if L.oracle_isError(r):
         return None, L.oracle_getErrorCode(r)
     return out.raw[:r], 0

@@ -521,6 +521,8 @@ typedef struct {
     U32 dictID;
     BYTE litBuffer[ZSTD_BLOCKSIZE_MAX + WILDCOPY_OVERLENGTH];
     oracle_trace* trace;
+    U32 magicless;             /* ZSTD_d_format = ZSTD_f_zstd1_magicless (zstd.pas:416-417) */
+    U32 forceIgnoreChecksum;   /* ZSTD_d_forceIgnoreChecksum (zstd_decompressf.pas:1796-1803) */
 } DCtx;
 
 static SeqTable LL_defaultDTable, OF_defaultDTable, ML_defaultDTable;  /* zstd_decompress_block.pas:29-125 */
@@ -917,10 +919,10 @@ typedef struct { U64 frameContentSize; U64 windowSize; U32 blockSizeMax; U32 dic
 static const size_t ZSTD_fcs_fieldSize[4] = {0, 2, 4, 8};
 static const size_t ZSTD_did_fieldSize[4] = {0, 1, 2, 4};
 
-/* zstd_decompressf.pas:246-279 */
-static size_t ZSTD_frameHeaderSize(const BYTE* src, size_t srcSize)
+/* zstd_decompressf.pas:246-279; minInputSize = ZSTD_startingInputLength(format) (:97-107): 5, or 1 without the magic number */
+static size_t ZSTD_frameHeaderSize(const BYTE* src, size_t srcSize, U32 magicless)
 {
-    size_t const minInputSize = 5;
+    size_t const minInputSize = magicless ? 1 : 5;
     if (srcSize < minInputSize) return ERR(srcSize_wrong);
     {   BYTE const fhd = src[minInputSize - 1];
         U32 const dictID = fhd & 3;
@@ -930,14 +932,14 @@ static size_t ZSTD_frameHeaderSize(const BYTE* src, size_t srcSize)
     }
 }
 /* zstd_decompressf.pas:281-395 ; returns 0 ok, >0 bytes wanted, or error */
-static size_t ZSTD_getFrameHeader(FrameHeader* zfh, const BYTE* src, size_t srcSize)
+static size_t ZSTD_getFrameHeader(FrameHeader* zfh, const BYTE* src, size_t srcSize, U32 magicless)
 {
     const BYTE* ip = src;
-    size_t const minInputSize = 5;
+    size_t const minInputSize = magicless ? 1 : 5;
     memset(zfh, 0, sizeof(*zfh));
     if (srcSize < minInputSize) return minInputSize;
-    if (rdLE32(src) != ZSTD_MAGICNUMBER) return ERR(prefix_unknown);   /* skippable frames are handled by the caller */
-    {   size_t const fhsize = ZSTD_frameHeaderSize(src, srcSize);
+    if (!magicless && rdLE32(src) != ZSTD_MAGICNUMBER) return ERR(prefix_unknown);   /* :301; skippable frames are handled by the caller */
+    {   size_t const fhsize = ZSTD_frameHeaderSize(src, srcSize, magicless);
         if (srcSize < fhsize) return fhsize;
         zfh->headerSize = (U32)fhsize;
     }
@@ -1076,11 +1078,12 @@ static size_t ZSTD_decompressFrame(DCtx* dctx, BYTE* dst, size_t dstCapacity, co
     BYTE* op = ostart;
     size_t remainingSrcSize = *srcSizePtr;
     FrameHeader fh;
-    if (remainingSrcSize < 6 + 3) return ERR(srcSize_wrong);
-    {   size_t const frameHeaderSize = ZSTD_frameHeaderSize(ip, 5);
+    size_t const prefix = dctx->magicless ? 1 : 5;            /* ZSTD_FRAMEHEADERSIZE_PREFIX(format), zstd.pas:615-628 */
+    if (remainingSrcSize < prefix + 1 + 3) return ERR(srcSize_wrong);   /* ZSTD_FRAMEHEADERSIZE_MIN(format) + block header (:755) */
+    {   size_t const frameHeaderSize = ZSTD_frameHeaderSize(ip, prefix, dctx->magicless);
         if (isErr(frameHeaderSize)) return frameHeaderSize;
         if (remainingSrcSize < frameHeaderSize + 3) return ERR(srcSize_wrong);
-        {   size_t const r = ZSTD_getFrameHeader(&fh, ip, frameHeaderSize);   /* ZSTD_decodeFrameHeader :541-563 */
+        {   size_t const r = ZSTD_getFrameHeader(&fh, ip, frameHeaderSize, dctx->magicless);   /* ZSTD_decodeFrameHeader :541-563 */
             if (isErr(r)) return r;
             if (r > 0) return ERR(srcSize_wrong);
             if (fh.dictID && (dctx->dictID != fh.dictID)) return ERR(dictionary_wrong);
@@ -1116,7 +1119,8 @@ static size_t ZSTD_decompressFrame(DCtx* dctx, BYTE* dst, size_t dstCapacity, co
     }
     if (fh.checksumFlag) {
         if (remainingSrcSize < 4) return ERR(checksum_wrong);
-        {   U32 const checkCalc = (U32)oracle_xxh64(ostart, (size_t)(op - ostart), 0);
+        if (!dctx->forceIgnoreChecksum) {   /* :819-825 */
+            U32 const checkCalc = (U32)oracle_xxh64(ostart, (size_t)(op - ostart), 0);
             U32 const checkRead = rdLE32(ip);
             if (checkRead != checkCalc) return ERR(checksum_wrong);
         }
@@ -1131,8 +1135,8 @@ static size_t decompressMultiFrame(DCtx* dctx, BYTE* dst, size_t dstCapacity, co
 {
     BYTE* const dststart = dst;
     int moreThan1Frame = 0;
-    while (srcSize >= 5) {
-        U32 const magicNumber = rdLE32(src);
+    while (srcSize >= (dctx->magicless ? 1u : 5u)) {    /* ZSTD_startingInputLength(format) (:857) */
+        U32 const magicNumber = srcSize >= 4 ? rdLE32(src) : 0;   /* the reference reads 4 bytes whatever is left; fewer cannot hold a frame either way */
         if ((magicNumber & ZSTD_MAGIC_SKIPPABLE_MASK) == ZSTD_MAGIC_SKIPPABLE_START) {
             size_t skippableSize;
             if (srcSize < 8) return ERR(srcSize_wrong);
@@ -1169,6 +1173,21 @@ size_t oracle_decompress_usingDict(void* dst, size_t dstCapacity, const void* sr
     free(dctx);
     return r;
 }
+/* The same with the decoder parameters of ZSTD_DCtx_setParameter (zstd_decompressf.pas:1763-1807) that change the
+ * result of a one-shot call: format (0 zstd1, 1 magicless) and forceIgnoreChecksum. */
+size_t oracle_decompress_advanced(void* dst, size_t dstCapacity, const void* src, size_t srcSize, const void* dict, size_t dictSize,
+                                  unsigned format, unsigned forceIgnoreChecksum)
+{
+    DCtx* const dctx = (DCtx*)calloc(1, sizeof(DCtx));
+    size_t r;
+    BYTE dummy;
+    if (!dctx) return ERR(GENERIC);
+    oracle_init();
+    dctx->magicless = format != 0; dctx->forceIgnoreChecksum = forceIgnoreChecksum != 0;
+    r = decompressMultiFrame(dctx, dst ? (BYTE*)dst : &dummy, dst ? dstCapacity : 0, (const BYTE*)src, srcSize, (const BYTE*)dict, dictSize);
+    free(dctx);
+    return r;
+}
 size_t oracle_decompress(void* dst, size_t dstCapacity, const void* src, size_t srcSize)
 {
     return oracle_decompress_usingDict(dst, dstCapacity, src, srcSize, NULL, 0);
@@ -1181,7 +1200,7 @@ U64 oracle_getFrameContentSize(const void* src, size_t srcSize)
 {
     FrameHeader zfh;
     if (srcSize >= 4 && (rdLE32((const BYTE*)src) & ZSTD_MAGIC_SKIPPABLE_MASK) == ZSTD_MAGIC_SKIPPABLE_START) return 0;
-    if (ZSTD_getFrameHeader(&zfh, (const BYTE*)src, srcSize) != 0) return ZSTD_CONTENTSIZE_UNKNOWN - 1;
+    if (ZSTD_getFrameHeader(&zfh, (const BYTE*)src, srcSize, 0) != 0) return ZSTD_CONTENTSIZE_UNKNOWN - 1;
     return zfh.frameContentSize;
 }
 /* ZSTD_findFrameCompressedSize (zstd_decompressf.pas:566-651) */
@@ -1199,7 +1218,7 @@ size_t oracle_findFrameCompressedSize(const void* srcv, size_t srcSize)
     {   const BYTE* ip = src;
         size_t remainingSize = srcSize;
         FrameHeader zfh;
-        {   size_t const ret = ZSTD_getFrameHeader(&zfh, src, srcSize);
+        {   size_t const ret = ZSTD_getFrameHeader(&zfh, src, srcSize, 0);
             if (isErr(ret)) return ret;
             if (ret > 0) return ERR(srcSize_wrong);
         }

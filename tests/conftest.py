@@ -69,3 +69,18 @@ def _built():
     build.build_corpus()
     build.build_oracle()
     yield
+
+
+# fixtures whose verdict depends on a decoder parameter (tools/gen_param_fixtures.py)
+def load_param_manifest():
+    with open(os.path.join(GOLD, "params", "manifest.json")) as f:
+        return json.load(f)
+
+
+PARAM_FRAMES = load_param_manifest()["frames"]
+PARAM_IDS = [e["name"] for e in PARAM_FRAMES]
+
+
+def read_param_frame(e) -> bytes:
+    with open(os.path.join(GOLD, "params", e["file"]), "rb") as f:
+        return f.read()

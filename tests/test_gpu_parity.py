@@ -418,3 +418,174 @@ def test_stream_with_dictionary(dctx):
         assert got == want and zeros == 1 and last == 0
     zs.close()
     dd.close()
+
+
+# ------------------------------------------------------------------ decoder parameters
+from conftest import PARAM_FRAMES, PARAM_IDS, read_param_frame  # noqa: E402
+
+
+def _with_params(dctx, e):
+    dctx.reset()
+    dctx.set_parameter(api.ZSTD_d_format, e["format"])
+    dctx.set_parameter(api.ZSTD_d_forceIgnoreChecksum, e["ignore_checksum"])
+
+
+@pytest.mark.parametrize("e", [x for x in PARAM_FRAMES if "stream_chunk" not in x], ids=[x["name"] for x in PARAM_FRAMES if "stream_chunk" not in x])
+def test_parameters_oneshot(dctx, e):
+    """ZSTD_d_format and ZSTD_d_forceIgnoreChecksum on the one-shot entry points: oracle and libzstd's recorded verdict."""
+    fr = read_param_frame(e)
+    d = read_dict(e.get("dict"))
+    want, werr = oracle.decompress(fr, e["capacity"], d, magicless=bool(e["format"]), ignore_checksum=bool(e["ignore_checksum"]))
+    try:
+        _with_params(dctx, e)
+        try:
+            got = api.ZSTD_decompress_usingDict(dctx, fr, e["capacity"], d) if d is not None else api.ZSTD_decompressDCtx(dctx, fr, e["capacity"])
+            gerr = 0
+        except api.ZstdError as ex:
+            got, gerr = None, ex.code
+    finally:
+        dctx.reset()
+    assert gerr == werr == e.get("error", 0)
+    if not gerr:
+        assert got == want
+        assert hashlib.sha256(got).hexdigest() == e["sha256"]
+
+
+@pytest.mark.parametrize("e", [x for x in PARAM_FRAMES if "stream_chunk" in x], ids=[x["name"] for x in PARAM_FRAMES if "stream_chunk" in x])
+def test_parameters_stream(dctx, e):
+    """The same parameters and ZSTD_d_windowLogMax on a stream fed the way the fixture was made (whole, or in chunks)."""
+    fr = read_param_frame(e)
+    try:
+        _with_params(dctx, e)
+        if e["stream_window_log_max"]:
+            dctx.set_parameter(api.ZSTD_d_windowLogMax, e["stream_window_log_max"])
+        zs = api.DStream(dctx)
+        try:
+            got, zeros, last = _stream_all(zs, fr, e["stream_chunk"] or len(fr), e["capacity"])
+            gerr = 0
+        except api.ZstdError as ex:
+            got, gerr = None, ex.code
+        zs.close()
+    finally:
+        dctx.reset()
+    assert gerr == e.get("error", 0)
+    if not gerr:
+        assert len(got) == e["size"] and hashlib.sha256(got).hexdigest() == e["sha256"]
+
+
+def test_parameters_device_walk(dctx):
+    """Batches pick the context's format and checksum policy up; the device walk builds the same descriptors."""
+    for fmt, ign in ((1, 0), (0, 1), (1, 1)):
+        es = [x for x in PARAM_FRAMES if "stream_chunk" not in x and "dict" not in x and x["format"] == fmt and x["ignore_checksum"] == ign
+              and "concat" not in x["name"] and "skippable" not in x["name"] and x["name"] != "ml_cut0"]
+        assert es
+        try:
+            dctx.reset()
+            dctx.set_parameter(api.ZSTD_d_format, fmt)
+            dctx.set_parameter(api.ZSTD_d_forceIgnoreChecksum, ign)
+            fin, (st, out) = _both_walks(dctx, [read_param_frame(e) for e in es], [e["capacity"] for e in es])
+        finally:
+            dctx.reset()
+        for i, e in enumerate(es):
+            assert int(st[i]["errorCode"]) == e.get("error", 0), e["name"]
+            if "error" not in e:
+                o = int(fin[i]["dstOff"])
+                assert hashlib.sha256(out[o:o + e["size"]].tobytes()).hexdigest() == e["sha256"], e["name"]
+
+
+def test_parameter_api(dctx):
+    """Bounds, defaults, out-of-range values, unknown parameters, stage checks and resets (zstd_decompressf.pas:1680-1826)."""
+    dctx.reset()
+    assert api.ZSTD_dParam_getBounds(api.ZSTD_d_windowLogMax) == (10, 31)
+    assert api.ZSTD_dParam_getBounds(api.ZSTD_d_format) == (0, 1)
+    assert api.ZSTD_dParam_getBounds(api.ZSTD_d_stableOutBuffer) == (0, 1)
+    assert api.ZSTD_dParam_getBounds(api.ZSTD_d_forceIgnoreChecksum) == (0, 1)
+    with pytest.raises(api.ZstdError) as ei:
+        api.ZSTD_dParam_getBounds(12345)
+    assert ei.value.code == 40
+    assert dctx.get_parameter(api.ZSTD_d_windowLogMax) == 27 and dctx.get_parameter(api.ZSTD_d_format) == 0
+    for p, v in ((api.ZSTD_d_windowLogMax, 9), (api.ZSTD_d_windowLogMax, 32), (api.ZSTD_d_format, 2), (api.ZSTD_d_forceIgnoreChecksum, -1)):
+        with pytest.raises(api.ZstdError) as ei:
+            dctx.set_parameter(p, v)
+        assert ei.value.code == 42
+    with pytest.raises(api.ZstdError) as ei:
+        dctx.set_parameter(777, 1)
+    assert ei.value.code == 40
+    dctx.set_parameter(api.ZSTD_d_windowLogMax, 23)
+    assert dctx.get_parameter(api.ZSTD_d_windowLogMax) == 23
+    dctx.set_parameter(api.ZSTD_d_windowLogMax, 0)          # 0 selects the default
+    assert dctx.get_parameter(api.ZSTD_d_windowLogMax) == 27
+    # inside a frame, parameters and the dictionary are frozen
+    e = next(x for x in FRAMES if x["name"] == "text4096_l3_c1")
+    fr = read_frame(e)
+    zs = api.DStream(dctx)
+    zs.decompress_stream(fr[:50], 100)
+    for call in (lambda: dctx.set_parameter(api.ZSTD_d_format, 1), lambda: dctx.ref_ddict(None), lambda: dctx.reset(api.ZSTD_reset_parameters)):
+        with pytest.raises(api.ZstdError) as ei:
+            call()
+        assert ei.value.code == 60
+    dctx.reset(api.ZSTD_reset_session_only)                 # drops the half-read frame
+    dctx.set_parameter(api.ZSTD_d_format, 1)
+    dctx.reset(api.ZSTD_reset_session_and_parameters)
+    assert dctx.get_parameter(api.ZSTD_d_format) == 0
+    got, zeros, last = _stream_all(zs, fr, 1000, 1 << 16)
+    assert got == oracle.decompress(fr, e["capacity"])[0]
+    zs.close()
+
+
+def test_ref_ddict_is_used_by_decompressDCtx(dctx):
+    d = read_dict("dict16k")
+    dd = api.DDict(dctx, d)
+    e = next(x for x in FRAMES if x.get("dict") == "dict16k" and "error" not in x)
+    fr = read_frame(e)
+    want, _ = oracle.decompress(fr, e["capacity"], d)
+    try:
+        dctx.ref_ddict(dd)
+        assert api.ZSTD_decompressDCtx(dctx, fr, e["capacity"]) == want
+        dctx.ref_ddict(None)
+        with pytest.raises(api.ZstdError) as ei:
+            api.ZSTD_decompressDCtx(dctx, fr, e["capacity"])
+        assert ei.value.code == 32
+        dctx.ref_ddict(dd)
+        dctx.reset(api.ZSTD_reset_parameters)              # clears the dictionary too
+        with pytest.raises(api.ZstdError):
+            api.ZSTD_decompressDCtx(dctx, fr, e["capacity"])
+    finally:
+        dctx.reset()
+        dd.close()
+
+
+def test_stable_out_buffer(dctx):
+    """ZSTD_d_stableOutBuffer: same buffer on every call of a frame, large enough for it (zstd_decompressf.pas:1913-1951)."""
+    import ctypes
+    e = next(x for x in FRAMES if x["name"] == "text128k_l3_c0")
+    fr = read_frame(e)
+    want, _ = oracle.decompress(fr, e["capacity"])
+    try:
+        dctx.reset()
+        dctx.set_parameter(api.ZSTD_d_stableOutBuffer, 1)
+        zs = api.DStream(dctx)
+        buf = ctypes.create_string_buffer(len(want) + 100)
+        pos, fed, r = 0, 0, 1
+        while r != 0:
+            r, used, pos = zs.decompress_stream_into(fr[fed:fed + 10000], buf, len(buf), pos)
+            fed += used
+        assert buf.raw[:pos] == want
+        # a different buffer in the middle of a frame
+        zs.decompress_stream_into(fr[:10000], buf, len(buf), 0)
+        other = ctypes.create_string_buffer(len(want) + 100)
+        with pytest.raises(api.ZstdError) as ei:
+            zs.decompress_stream_into(fr[10000:20000], other, len(other), 0)
+        assert ei.value.code == 104
+        zs.reset()
+        # too small for the frame
+        small = ctypes.create_string_buffer(1000)
+        with pytest.raises(api.ZstdError) as ei:
+            fed, r = 0, 1
+            while r != 0:
+                r, used, _ = zs.decompress_stream_into(fr[fed:fed + 50000], small, len(small), 0)
+                fed += used
+        assert ei.value.code == 70
+        zs.close()
+    finally:
+        dctx.reset()

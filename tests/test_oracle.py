@@ -46,3 +46,18 @@ def test_trace_consistency():
         assert int(s[:, 0].sum()) <= int(lit)
         pos += n
     assert sum(int(x) for x in t["blk_regen"]) == e["size"]
+
+
+from conftest import PARAM_FRAMES, read_param_frame  # noqa: E402
+
+_ONESHOT_PARAM = [x for x in PARAM_FRAMES if "stream_chunk" not in x]
+
+
+@pytest.mark.parametrize("e", _ONESHOT_PARAM, ids=[x["name"] for x in _ONESHOT_PARAM])
+def test_oracle_matches_libzstd_under_decoder_parameters(e):
+    """ZSTD_d_format (magicless frames) and ZSTD_d_forceIgnoreChecksum: libzstd 1.4.8's verdict under the parameter."""
+    out, err = oracle.decompress(read_param_frame(e), e["capacity"], read_dict(e.get("dict")),
+                                 magicless=bool(e["format"]), ignore_checksum=bool(e["ignore_checksum"]))
+    assert err == e.get("error", 0)
+    if not err:
+        assert len(out) == e["size"] and hashlib.sha256(out).hexdigest() == e["sha256"]

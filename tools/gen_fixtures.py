@@ -125,7 +125,8 @@ def huf12_frame(seed: int, n: int, single_stream: bool):
 def main():
     os.makedirs(OUT, exist_ok=True)
     for f in os.listdir(OUT):
-        os.remove(os.path.join(OUT, f))
+        if os.path.isfile(os.path.join(OUT, f)):      # tests/golden/params/ belongs to tools/gen_param_fixtures.py
+            os.remove(os.path.join(OUT, f))
     z = corpus.SystemZstd()
     assert z.version == "1.4.8", z.version
     manifest = {"generator": "tools/gen_fixtures.py", "libzstd": z.version, "frames": [], "dicts": {}}

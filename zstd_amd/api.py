@@ -65,10 +65,22 @@ EXPORTS = (
     "zstdgpu_batch_descriptorDigest", "zstdgpu_batch_destroy",
     "zstdgpu_createDStream", "zstdgpu_freeDStream", "zstdgpu_initDStream", "zstdgpu_initDStream_usingDDict", "zstdgpu_resetDStream",
     "zstdgpu_decompressStream",
+    "zstdgpu_dParam_getBounds", "zstdgpu_DCtx_setParameter", "zstdgpu_DCtx_getParameter", "zstdgpu_DCtx_refDDict", "zstdgpu_DCtx_reset",
     "zstdgpu_batch_decode", "zstdgpu_batch_status", "zstdgpu_batch_nFrames", "zstdgpu_batch_nBlocks", "zstdgpu_batch_srcBytes",
     "zstdgpu_batch_scratchBytes", "zstdgpu_batch_set_profiling", "zstdgpu_batch_stage_ms", "zstdgpu_stage_kernel_name",
     "zstdgpu_xxh64Batch", "zstdgpu_batch_blockInfo", "zstdgpu_batch_copyLiterals", "zstdgpu_batch_copySequences",
 )
+
+
+class Bounds(ctypes.Structure):
+    """zstdgpu_bounds (ZSTD_bounds)."""
+    _fields_ = [("error", ctypes.c_size_t), ("lowerBound", ctypes.c_int), ("upperBound", ctypes.c_int)]
+
+
+# zstdgpu_dParameter / zstdgpu_ResetDirective
+ZSTD_d_windowLogMax, ZSTD_d_format, ZSTD_d_stableOutBuffer, ZSTD_d_forceIgnoreChecksum = 100, 1000, 1001, 1002
+ZSTD_f_zstd1, ZSTD_f_zstd1_magicless = 0, 1
+ZSTD_reset_session_only, ZSTD_reset_parameters, ZSTD_reset_session_and_parameters = 1, 2, 3
 
 
 def lib():
@@ -114,6 +126,11 @@ def lib():
     proto("zstdgpu_initDStream_usingDDict", sz, vp, vp)
     proto("zstdgpu_resetDStream", sz, vp)
     proto("zstdgpu_decompressStream", sz, vp, vp, vp)
+    proto("zstdgpu_dParam_getBounds", Bounds, ci)
+    proto("zstdgpu_DCtx_setParameter", sz, vp, ci, ci)
+    proto("zstdgpu_DCtx_getParameter", sz, vp, ci, P(ci))
+    proto("zstdgpu_DCtx_refDDict", sz, vp, vp)
+    proto("zstdgpu_DCtx_reset", sz, vp, ci)
     proto("zstdgpu_batch_destroy", None, vp)
     proto("zstdgpu_batch_decode", sz, vp, vp, vp, vp)
     proto("zstdgpu_batch_status", sz, vp, vp)
@@ -130,6 +147,13 @@ def lib():
     proto("zstdgpu_batch_copySequences", sz, vp, u32, vp, sz)
     _lib = L
     return L
+
+
+def ZSTD_dParam_getBounds(param: int):
+    """Returns (lowerBound, upperBound); raises ZstdError for an unknown parameter."""
+    b = lib().zstdgpu_dParam_getBounds(param)
+    _check(b.error)
+    return b.lowerBound, b.upperBound
 
 
 def _check(r: int) -> int:
@@ -165,6 +189,22 @@ class DCtx:
         if not self.h:
             raise RuntimeError(f"zstdgpu_create({device}) failed: no usable GPU")
         self.device = device
+
+    # ZSTD_DCtx_setParameter / getParameter / refDDict / reset (decompress/zstd_decompressf.pas:1641-1826)
+    def set_parameter(self, param: int, value: int):
+        _check(lib().zstdgpu_DCtx_setParameter(self.h, param, value))
+
+    def get_parameter(self, param: int) -> int:
+        v = ctypes.c_int(0)
+        _check(lib().zstdgpu_DCtx_getParameter(self.h, param, ctypes.byref(v)))
+        return v.value
+
+    def ref_ddict(self, ddict):
+        self._ref = ddict      # keep it alive
+        _check(lib().zstdgpu_DCtx_refDDict(self.h, ddict.h if ddict else None))
+
+    def reset(self, directive: int = ZSTD_reset_session_and_parameters):
+        _check(lib().zstdgpu_DCtx_reset(self.h, directive))
 
     def close(self):
         if self.h:
@@ -381,6 +421,15 @@ class DStream:
         ob = _OutBuffer(ctypes.cast(dst, ctypes.c_void_p), out_room, 0)
         r = _check(lib().zstdgpu_decompressStream(self.h, ctypes.byref(ob), ctypes.byref(ib)))
         return r, ib.pos, dst.raw[:ob.pos]
+
+    def decompress_stream_into(self, data: bytes, dst, size: int, pos: int):
+        """The same into a caller-held buffer `dst` (ctypes array) at `pos`, as ZSTD_d_stableOutBuffer wants it:
+        returns (return value, bytes consumed, new pos)."""
+        src = ctypes.create_string_buffer(data, len(data)) if data else ctypes.create_string_buffer(1)
+        ib = _InBuffer(ctypes.cast(src, ctypes.c_void_p), len(data), 0)
+        ob = _OutBuffer(ctypes.cast(dst, ctypes.c_void_p), size, pos)
+        r = _check(lib().zstdgpu_decompressStream(self.h, ctypes.byref(ob), ctypes.byref(ib)))
+        return r, ib.pos, ob.pos
 
     def close(self):
         if self.h:

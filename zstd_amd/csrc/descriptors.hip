@@ -33,24 +33,25 @@ DEVI uint64_t g64(const uint8_t* p) { return (uint64_t)g32(p) | ((uint64_t)g32(p
 // every block slot in order.  Fills the frame descriptor except firstBlock; `slots` = block slots the frame takes in
 // the block array (they stay even when the frame ends up with an error and nBlocks = 0, as in the host builder).
 template <typename Emit>
-DEVI void walk_frame(const uint8_t* base, uint64_t srcBytes, FrameIn const in, uint32_t batchDictID, uint32_t haveDict,
+DEVI void walk_frame(const uint8_t* base, uint64_t srcBytes, FrameIn const in, uint32_t batchDictID, uint32_t opts,
                      DevFrame& f, uint32_t& slots, Emit emit)
 {
     f.dstOff = in.dstOff; f.dstCapacity = in.dstCapacity; f.contentSize = kContentSizeUnknown;
-    f.firstBlock = 0; f.nBlocks = 0; f.checksumFlag = 0; f.checksum = 0; f.hostError = 0; f.useDict = haveDict;
+    f.firstBlock = 0; f.nBlocks = 0; f.checksumFlag = 0; f.checksum = 0; f.hostError = 0; f.useDict = opts & kOptDict;
+    uint32_t const pre = (opts & kOptMagicless) ? 1u : 5u;      // bytes up to and including the descriptor byte
     slots = 0;
     if (in.srcOff > srcBytes || in.srcSize > srcBytes - in.srcOff) { f.hostError = E_srcSize_wrong; return; }
     const uint8_t* const src = base + in.srcOff;
     uint64_t remaining = in.srcSize;
-    if (remaining < 6 + 3) { f.hostError = E_srcSize_wrong; return; }
-    uint32_t const fhd = src[4];
+    if (remaining < pre + 1 + 3) { f.hostError = E_srcSize_wrong; return; }
+    uint32_t const fhd = src[pre - 1];
     uint32_t const dictIDSizeCode = fhd & 3, singleSegment = (fhd >> 5) & 1, fcsID = fhd >> 6;
-    uint32_t const fhsize = 5 + (singleSegment ? 0u : 1u) + (dictIDSizeCode == 3 ? 4u : dictIDSizeCode) +
+    uint32_t const fhsize = pre + (singleSegment ? 0u : 1u) + (dictIDSizeCode == 3 ? 4u : dictIDSizeCode) +
                             (fcsID == 0 ? 0u : fcsID == 1 ? 2u : fcsID == 2 ? 4u : 8u) + ((singleSegment && !fcsID) ? 1u : 0u);
     if (remaining < (uint64_t)fhsize + 3) { f.hostError = E_srcSize_wrong; return; }
-    if (g32(src) != kMagic) { f.hostError = E_prefix_unknown; return; }
+    if (pre == 5 && g32(src) != kMagic) { f.hostError = E_prefix_unknown; return; }
     if (fhd & 0x08) { f.hostError = E_frameParameter_unsupported; return; }
-    uint32_t pos = 5;
+    uint32_t pos = pre;
     if (!singleSegment) {
         uint32_t const wl = src[pos++];
         if ((wl >> 3) + 10 > kWindowLogMax) { f.hostError = E_frameParameter_windowTooLarge; return; }
@@ -89,7 +90,7 @@ DEVI void walk_frame(const uint8_t* base, uint64_t srcBytes, FrameIn const in, u
     f.nBlocks = slots;
     if (!stopped && ((fhd >> 2) & 1)) {
         if (remaining < 4) f.checksumFlag = 2;   // trailer missing: checksum_wrong once everything else passed
-        else { f.checksumFlag = 1; f.checksum = g32(src + ip); ip += 4; }
+        else { f.checksumFlag = (opts & kOptIgnoreChecksum) ? 0u : 1u; f.checksum = g32(src + ip); ip += 4; }
     }
     // one entry is exactly one frame: bytes after it are an error
     if (ip != in.srcSize && f.checksumFlag != 2 && !stopped) f.hostError = E_srcSize_wrong;
@@ -154,13 +155,13 @@ DEVI void parse_sections(const uint8_t* payload, DevBlock& d)
 
 // ---- launch 1: frame descriptors (all but firstBlock) and the block slots of every frame
 __global__ __launch_bounds__(64) void k_scan_frames(const uint8_t* src, uint64_t srcBytes, const FrameIn* in, uint32_t nFrames,
-                                                    uint32_t batchDictID, uint32_t haveDict, DevFrame* frames, uint32_t* slots)
+                                                    uint32_t batchDictID, uint32_t opts, DevFrame* frames, uint32_t* slots)
 {
     uint32_t const fi = blockIdx.x * 64 + threadIdx.x;
     if (fi >= nFrames) return;
     DevFrame f;
     uint32_t n;
-    walk_frame(src, srcBytes, in[fi], batchDictID, haveDict, f, n, [](uint32_t, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t) {});
+    walk_frame(src, srcBytes, in[fi], batchDictID, opts, f, n, [](uint32_t, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t) {});
     frames[fi] = f;
     slots[fi] = n;
 }
@@ -213,7 +214,7 @@ __global__ __launch_bounds__(kScanThreads) void k_first_blocks(const uint32_t* s
 // flags: bit 0 literal job, bit 1 sequence job.  The block array was cleared beforehand: the slots of frames that end up
 // with an error stay zero.
 __global__ __launch_bounds__(64) void k_fill_blocks(const uint8_t* src, uint64_t srcBytes, const FrameIn* in, uint32_t nFrames,
-                                                    uint32_t batchDictID, uint32_t haveDict, uint32_t dictEntropy, const DevFrame* frames,
+                                                    uint32_t batchDictID, uint32_t opts, uint32_t dictEntropy, const DevFrame* frames,
                                                     DevBlock* blocks, uint8_t* flags)
 {
     uint32_t const fi = blockIdx.x * 64 + threadIdx.x;
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(64) void k_fill_blocks(const uint8_t* src, uint64_t
     bool dead = false;      // an error found here ends the frame: later blocks are never reached
     DevFrame f;
     uint32_t n;
-    walk_frame(src, srcBytes, in[fi], batchDictID, haveDict, f, n,
+    walk_frame(src, srcBytes, in[fi], batchDictID, opts, f, n,
                [&](uint32_t i, uint64_t off, uint32_t cSize, uint32_t origSize, uint32_t type, uint32_t last, uint32_t err) {
         uint32_t const b = first + i;
         DevBlock d = {};
@@ -300,19 +301,19 @@ __global__ __launch_bounds__(kScanThreads) void k_block_offsets(DevBlock* blocks
 
 }  // namespace
 
-void launch_scan_frames(const uint8_t* src, uint64_t srcBytes, const FrameIn* in, uint32_t nFrames, uint32_t batchDictID, uint32_t haveDict,
+void launch_scan_frames(const uint8_t* src, uint64_t srcBytes, const FrameIn* in, uint32_t nFrames, uint32_t batchDictID, uint32_t opts,
                         DevFrame* frames, uint32_t* slots, uint64_t* totals, void* stream)
 {
-    if (nFrames) hipLaunchKernelGGL(k_scan_frames, dim3((nFrames + 63) / 64), dim3(64), 0, (hipStream_t)stream, src, srcBytes, in, nFrames, batchDictID, haveDict, frames, slots);
+    if (nFrames) hipLaunchKernelGGL(k_scan_frames, dim3((nFrames + 63) / 64), dim3(64), 0, (hipStream_t)stream, src, srcBytes, in, nFrames, batchDictID, opts, frames, slots);
     hipMemsetAsync(totals, 0, 8 * sizeof(uint64_t), (hipStream_t)stream);
     hipLaunchKernelGGL(k_first_blocks, dim3(1), dim3(kScanThreads), 0, (hipStream_t)stream, slots, in, nFrames, frames, totals);
 }
 
-void launch_fill_blocks(const uint8_t* src, uint64_t srcBytes, const FrameIn* in, uint32_t nFrames, uint32_t batchDictID, uint32_t haveDict,
+void launch_fill_blocks(const uint8_t* src, uint64_t srcBytes, const FrameIn* in, uint32_t nFrames, uint32_t batchDictID, uint32_t opts,
                         uint32_t dictEntropy, const DevFrame* frames, DevBlock* blocks, uint8_t* flags, uint32_t nBlocks,
                         uint32_t* litJobs, uint32_t* seqJobs, uint64_t* totals, void* stream)
 {
-    if (nFrames) hipLaunchKernelGGL(k_fill_blocks, dim3((nFrames + 63) / 64), dim3(64), 0, (hipStream_t)stream, src, srcBytes, in, nFrames, batchDictID, haveDict, dictEntropy, frames, blocks, flags);
+    if (nFrames) hipLaunchKernelGGL(k_fill_blocks, dim3((nFrames + 63) / 64), dim3(64), 0, (hipStream_t)stream, src, srcBytes, in, nFrames, batchDictID, opts, dictEntropy, frames, blocks, flags);
     hipLaunchKernelGGL(k_block_offsets, dim3(1), dim3(kScanThreads), 0, (hipStream_t)stream, blocks, flags, nBlocks, litJobs, seqJobs, totals);
 }
 

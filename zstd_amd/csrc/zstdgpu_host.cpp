@@ -38,25 +38,28 @@ struct FrameHeader {
 };
 
 // ZSTD_frameHeaderSize_internal (zstd_decompressf.pas:246-279); srcSize >= 5 required
-size_t frame_header_size(const uint8_t* src, size_t srcSize)
+// `magicless`: ZSTD_f_zstd1_magicless, the frame starts at its descriptor byte (ZSTD_startingInputLength :97-107)
+size_t frame_header_size(const uint8_t* src, size_t srcSize, bool magicless = false)
 {
     static const size_t fcs[4] = {0, 2, 4, 8}, did[4] = {0, 1, 2, 4};
-    if (srcSize < 5) return mkerr(E_srcSize_wrong);
-    uint8_t const fhd = src[4];
+    size_t const pre = magicless ? 1 : 5;
+    if (srcSize < pre) return mkerr(E_srcSize_wrong);
+    uint8_t const fhd = src[pre - 1];
     uint32_t const singleSegment = (fhd >> 5) & 1, fcsId = fhd >> 6;
-    return 5 + !singleSegment + did[fhd & 3] + fcs[fcsId] + (singleSegment && !fcsId);
+    return pre + !singleSegment + did[fhd & 3] + fcs[fcsId] + (singleSegment && !fcsId);
 }
 
 // ZSTD_getFrameHeader_advanced (zstd_decompressf.pas:281-395): 0 ok, >0 bytes wanted, or error
-size_t get_frame_header(FrameHeader& h, const uint8_t* src, size_t srcSize)
+size_t get_frame_header(FrameHeader& h, const uint8_t* src, size_t srcSize, bool magicless = false)
 {
-    if (srcSize < 5) return 5;
-    if (rd32(src) != kMagic) return mkerr(E_prefix_unknown);
-    size_t const fhsize = frame_header_size(src, srcSize);
+    size_t const pre = magicless ? 1 : 5;
+    if (srcSize < pre) return pre;
+    if (!magicless && rd32(src) != kMagic) return mkerr(E_prefix_unknown);
+    size_t const fhsize = frame_header_size(src, srcSize, magicless);
     if (srcSize < fhsize) return fhsize;
     h.headerSize = (uint32_t)fhsize;
-    uint8_t const fhd = src[4];
-    size_t pos = 5;
+    uint8_t const fhd = src[pre - 1];
+    size_t pos = pre;
     uint32_t const dictIDSizeCode = fhd & 3, singleSegment = (fhd >> 5) & 1, fcsID = fhd >> 6;
     h.checksumFlag = (fhd >> 2) & 1;
     if (fhd & 0x08) return mkerr(E_frameParameter_unsupported);
@@ -96,9 +99,12 @@ size_t skippable_size(const uint8_t* src, size_t srcSize)
 
 // Walk one frame: header, then every block header (ZSTD_decompressFrame :734-808 without the decoding,
 // i.e. the loop of ZSTD_findFrameSizeInfo :566-639).  Appends block descriptors; returns bytes consumed.
+// opts: kOptMagicless (frame format), kOptIgnoreChecksum (the trailer is skipped, not compared: :815-828)
 size_t walk_frame(const uint8_t* base, const zstdgpu_frame_in& in, uint32_t frameIdx, uint32_t batchDictID,
-                  zstdgpu_frame_desc& fd, std::vector<zstdgpu_block_desc>* blocks, size_t& nBlocksOut)
+                  zstdgpu_frame_desc& fd, std::vector<zstdgpu_block_desc>* blocks, size_t& nBlocksOut, uint32_t opts = 0)
 {
+    bool const magicless = (opts & kOptMagicless) != 0;
+    size_t const pre = magicless ? 1 : 5;
     const uint8_t* const src = base + in.srcOff;
     size_t remaining = in.srcSize;
     fd = zstdgpu_frame_desc{};
@@ -106,11 +112,11 @@ size_t walk_frame(const uint8_t* base, const zstdgpu_frame_in& in, uint32_t fram
     fd.contentSize = ZSTDGPU_CONTENTSIZE_UNKNOWN;
     fd.firstBlock = (uint32_t)nBlocksOut;
     auto fail = [&](uint32_t code) { fd.hostError = code; fd.nBlocks = 0; nBlocksOut = fd.firstBlock; if (blocks) blocks->resize(fd.firstBlock); return (size_t)0; };
-    if (remaining < 6 + 3) return fail(E_srcSize_wrong);
-    size_t const fhsize = frame_header_size(src, 5);
+    if (remaining < pre + 1 + 3) return fail(E_srcSize_wrong);       // ZSTD_FRAMEHEADERSIZE_MIN(format) + block header (:755)
+    size_t const fhsize = frame_header_size(src, pre, magicless);
     if (remaining < fhsize + 3) return fail(E_srcSize_wrong);
     FrameHeader fh;
-    size_t const r = get_frame_header(fh, src, fhsize);
+    size_t const r = get_frame_header(fh, src, fhsize, magicless);
     if (iserr(r)) return fail((uint32_t)(0 - r));
     if (r > 0) return fail(E_srcSize_wrong);
     if (fh.dictID && fh.dictID != batchDictID) return fail(E_dictionary_wrong);   // ZSTD_decodeFrameHeader :541-563
@@ -143,7 +149,7 @@ size_t walk_frame(const uint8_t* base, const zstdgpu_frame_in& in, uint32_t fram
     fd.nBlocks = (uint32_t)nBlocksOut - fd.firstBlock;
     if (fh.checksumFlag) {
         if (remaining < 4) fd.checksumFlag = 2;   // trailer missing: checksum_wrong once everything else passed (:817)
-        else { fd.checksumFlag = 1; fd.checksum = rd32(src + ip); ip += 4; remaining -= 4; }
+        else { fd.checksumFlag = (opts & kOptIgnoreChecksum) ? 0 : 1; fd.checksum = rd32(src + ip); ip += 4; remaining -= 4; }
     }
     return ip;
 }
@@ -160,6 +166,14 @@ struct zstdgpu_ctx {
     // literal/sequence scratch costs tens of milliseconds; a steady stream of batches should not pay it again)
     struct Spare { void* p; size_t bytes; };
     std::vector<Spare> spare;
+    // decoder parameters (ZSTD_DCtx_resetParameters, zstd_decompressf.pas:131-139) and the referenced dictionary
+    uint32_t format = 0;                          // ZSTD_f_zstd1 / ZSTD_f_zstd1_magicless
+    uint64_t maxWindowSize = (1ull << 27) + 1;    // ZSTD_MAXWINDOWSIZE_DEFAULT (:51)
+    uint32_t stableOut = 0, ignoreChecksum = 0;
+    const zstdgpu_ddict* refDDict = nullptr;
+    std::vector<zstdgpu_dstream*> streams;        // streams opened on this context
+    uint32_t opts() const { return (format ? kOptMagicless : 0u) | (ignoreChecksum ? kOptIgnoreChecksum : 0u); }
+    void reset_parameters() { format = 0; maxWindowSize = (1ull << 27) + 1; stableOut = 0; ignoreChecksum = 0; }
 };
 
 struct zstdgpu_ddict {
@@ -320,6 +334,10 @@ extern "C" const char* zstdgpu_getErrorName(size_t code)
         case 22: return "Restored data doesn't match checksum";
         case 30: return "Dictionary is corrupted";
         case 32: return "Dictionary mismatch";
+        case 40: return "Unsupported parameter";
+        case 42: return "Parameter is out of bound";
+        case 60: return "Operation not authorized at current processing stage";
+        case 104: return "Destination buffer is wrong";
         case 64: return "Allocation error : not enough memory";
         case 70: return "Destination buffer is too small";
         case 72: return "Src size is incorrect";
@@ -347,20 +365,30 @@ extern "C" void zstdgpu_destroy(zstdgpu_ctx* ctx)
 }
 
 // ===================================================================== header queries
-extern "C" unsigned long long zstdgpu_getFrameContentSize(const void* src, size_t srcSize)
+namespace {
+unsigned long long frame_content_size(const uint8_t* s, size_t srcSize, bool magicless)
 {
-    const uint8_t* s = (const uint8_t*)src;
     if (srcSize >= 4 && (rd32(s) & kMagicSkipMask) == kMagicSkipStart) return 0;   // :374-385 (skippable: content size 0)
     FrameHeader h;
-    if (get_frame_header(h, s, srcSize) != 0) return ZSTDGPU_CONTENTSIZE_ERROR;
+    if (get_frame_header(h, s, srcSize, magicless) != 0) return ZSTDGPU_CONTENTSIZE_ERROR;
     return h.contentSize;
+}
+size_t find_frame_size(const uint8_t* src, size_t srcSize, bool magicless);
+}  // namespace
+extern "C" unsigned long long zstdgpu_getFrameContentSize(const void* src, size_t srcSize)
+{
+    return frame_content_size((const uint8_t*)src, srcSize, false);
 }
 extern "C" size_t zstdgpu_findFrameCompressedSize(const void* srcv, size_t srcSize)
 {
-    const uint8_t* src = (const uint8_t*)srcv;
+    return find_frame_size((const uint8_t*)srcv, srcSize, false);
+}
+namespace {
+size_t find_frame_size(const uint8_t* src, size_t srcSize, bool magicless)
+{
     if (srcSize >= 8 && (rd32(src) & kMagicSkipMask) == kMagicSkipStart) return skippable_size(src, srcSize);
     FrameHeader h;
-    size_t const r = get_frame_header(h, src, srcSize);
+    size_t const r = get_frame_header(h, src, srcSize, magicless);
     if (iserr(r)) return r;
     if (r > 0) return mkerr(E_srcSize_wrong);
     size_t ip = h.headerSize, remaining = srcSize - h.headerSize;
@@ -377,6 +405,7 @@ extern "C" size_t zstdgpu_findFrameCompressedSize(const void* srcv, size_t srcSi
     if (h.checksumFlag) { if (remaining < 4) return mkerr(E_srcSize_wrong); ip += 4; }
     return ip;
 }
+}  // namespace
 extern "C" unsigned zstdgpu_getDictID_fromDict(const void* dict, size_t dictSize)
 {
     if (dictSize < 8 || rd32((const uint8_t*)dict) != kMagicDict) return 0;
@@ -420,14 +449,16 @@ extern "C" zstdgpu_ddict* zstdgpu_createDDict(zstdgpu_ctx* ctx, const void* dict
 extern "C" void zstdgpu_freeDDict(zstdgpu_ddict* d)
 {
     if (!d) return;
+    if (d->ctx && d->ctx->refDDict == d) d->ctx->refDDict = nullptr;   // a freed dictionary is no longer referenced
     set_device(d->ctx);
     hipFree(d->dBytes); hipFree(d->dDict);
     delete d;
 }
 
 // ===================================================================== descriptor builder
-extern "C" size_t zstdgpu_buildDescriptors(const void* hostSrc, size_t srcBytes, const zstdgpu_frame_in* in, uint32_t nFrames,
-                                           zstdgpu_frame_desc* frames, zstdgpu_block_desc* blocks, size_t blockCapacity)
+namespace {
+size_t build_descriptors(const void* hostSrc, size_t srcBytes, const zstdgpu_frame_in* in, uint32_t nFrames,
+                         zstdgpu_frame_desc* frames, zstdgpu_block_desc* blocks, size_t blockCapacity, uint32_t opts)
 {
     // dictID checks need the batch dictionary: done again in zstdgpu_batch_create; here any dictID is accepted
     std::vector<zstdgpu_block_desc> tmp;
@@ -441,8 +472,8 @@ extern "C" size_t zstdgpu_buildDescriptors(const void* hostSrc, size_t srcBytes,
             // peek the dictID so the walk does not reject it; the batch compares it with its dictionary
             FrameHeader fh;
             uint32_t did = 0;
-            if (get_frame_header(fh, (const uint8_t*)hostSrc + in[i].srcOff, in[i].srcSize) == 0) did = fh.dictID;
-            size_t const used = walk_frame((const uint8_t*)hostSrc, in[i], i, did, fd, &tmp, nBlocks);
+            if (get_frame_header(fh, (const uint8_t*)hostSrc + in[i].srcOff, in[i].srcSize, (opts & kOptMagicless) != 0) == 0) did = fh.dictID;
+            size_t const used = walk_frame((const uint8_t*)hostSrc, in[i], i, did, fd, &tmp, nBlocks, opts);
             if (!fd.hostError && used != in[i].srcSize && fd.checksumFlag != 2 && !(fd.nBlocks && tmp.back().blockType == BT_STOP))
                 { fd.hostError = E_srcSize_wrong; }   // bytes after the frame: one entry is exactly one frame
         }
@@ -453,6 +484,12 @@ extern "C" size_t zstdgpu_buildDescriptors(const void* hostSrc, size_t srcBytes,
         if (nBlocks) memcpy(blocks, tmp.data(), nBlocks * sizeof(zstdgpu_block_desc));
     }
     return nBlocks;
+}
+}  // namespace
+extern "C" size_t zstdgpu_buildDescriptors(const void* hostSrc, size_t srcBytes, const zstdgpu_frame_in* in, uint32_t nFrames,
+                                           zstdgpu_frame_desc* frames, zstdgpu_block_desc* blocks, size_t blockCapacity)
+{
+    return build_descriptors(hostSrc, srcBytes, in, nFrames, frames, blocks, blockCapacity, 0);
 }
 
 // ===================================================================== batch
@@ -538,11 +575,13 @@ extern "C" zstdgpu_batch* zstdgpu_batch_create(zstdgpu_ctx* ctx, const void* hos
 extern "C" zstdgpu_batch* zstdgpu_batch_create_from_frames(zstdgpu_ctx* ctx, const void* hostSrc, size_t srcBytes,
                                                            const zstdgpu_frame_in* in, uint32_t nFrames, const zstdgpu_ddict* ddict)
 {
+    if (!ctx) return nullptr;
+    uint32_t const opts = ctx->opts();      // the context's frame format and checksum policy apply to the batch
     std::vector<zstdgpu_frame_desc> frames(nFrames);
-    size_t const n = zstdgpu_buildDescriptors(hostSrc, srcBytes, in, nFrames, frames.data(), nullptr, 0);
+    size_t const n = build_descriptors(hostSrc, srcBytes, in, nFrames, frames.data(), nullptr, 0, opts);
     if (iserr(n)) return nullptr;
     std::vector<zstdgpu_block_desc> blocks(n ? n : 1);
-    size_t const n2 = zstdgpu_buildDescriptors(hostSrc, srcBytes, in, nFrames, frames.data(), blocks.data(), blocks.size());
+    size_t const n2 = build_descriptors(hostSrc, srcBytes, in, nFrames, frames.data(), blocks.data(), blocks.size(), opts);
     if (iserr(n2)) return nullptr;
     return zstdgpu_batch_create(ctx, hostSrc, srcBytes, frames.data(), nFrames, blocks.data(), (uint32_t)n2, ddict);
 }
@@ -568,7 +607,7 @@ extern "C" zstdgpu_batch* zstdgpu_batch_create_on_device(zstdgpu_ctx* ctx, const
               dalloc(dIn, nFrames, tmpAcct) && dalloc(dSlots, nFrames, tmpAcct) && dalloc(dTotals, 8, tmpAcct);
     ok = ok && (nFrames == 0 || hipMemcpy(dIn, in, (size_t)nFrames * sizeof(FrameIn), hipMemcpyHostToDevice) == hipSuccess);
     if (ok) {
-        launch_scan_frames((const uint8_t*)devSrc, srcBytes, dIn, nFrames, batchDictID, ddict ? 1u : 0u, B->dFrames, dSlots, dTotals, nullptr);
+        launch_scan_frames((const uint8_t*)devSrc, srcBytes, dIn, nFrames, batchDictID, (ddict ? (uint32_t)kOptDict : 0u) | ctx->opts(), B->dFrames, dSlots, dTotals, nullptr);
         ok = hipMemcpy(totals, dTotals, sizeof(totals), hipMemcpyDeviceToHost) == hipSuccess && totals[0] <= 0x7FFFFFFFull;
         nBlocks = (uint32_t)totals[0];
     }
@@ -576,7 +615,7 @@ extern "C" zstdgpu_batch* zstdgpu_batch_create_on_device(zstdgpu_ctx* ctx, const
          dalloc(B->dLitJobs, nBlocks, B->scratchBytes) && dalloc(B->dSeqJobs, nBlocks, B->scratchBytes);
     ok = ok && hipMemset(B->dBlocks, 0, (size_t)(nBlocks ? nBlocks : 1) * sizeof(DevBlock)) == hipSuccess && hipMemset(dFlags, 0, nBlocks ? nBlocks : 1) == hipSuccess;
     if (ok) {
-        launch_fill_blocks((const uint8_t*)devSrc, srcBytes, dIn, nFrames, batchDictID, ddict ? 1u : 0u, (ddict && ddict->hasEntropy) ? 1u : 0u,
+        launch_fill_blocks((const uint8_t*)devSrc, srcBytes, dIn, nFrames, batchDictID, (ddict ? (uint32_t)kOptDict : 0u) | ctx->opts(), (ddict && ddict->hasEntropy) ? 1u : 0u,
                            B->dFrames, B->dBlocks, dFlags, nBlocks, B->dLitJobs, B->dSeqJobs, dTotals, nullptr);
         ok = hipMemcpy(totals, dTotals, sizeof(totals), hipMemcpyDeviceToHost) == hipSuccess;
     }
@@ -853,26 +892,27 @@ size_t decompress_multi(zstdgpu_ctx* ctx, void* dst, size_t dstCapacity, const v
     size_t ip = 0;
     size_t tailErr = 0;               // error to report once the frames before it decoded fine
     bool more1 = false;
-    while (srcSize - ip >= 5) {
-        uint32_t const magic = rd32(src + ip);
+    bool const magicless = ctx->format != 0;
+    while (srcSize - ip >= (magicless ? 1u : 5u)) {      // ZSTD_startingInputLength(format) (:857)
+        uint32_t const magic = srcSize - ip >= 4 ? rd32(src + ip) : 0;
         if ((magic & kMagicSkipMask) == kMagicSkipStart) {
             size_t const sk = skippable_size(src + ip, srcSize - ip);
             if (iserr(sk)) { tailErr = sk; break; }
             ip += sk;
             continue;
         }
-        size_t const fsz = zstdgpu_findFrameCompressedSize(src + ip, srcSize - ip);
+        size_t const fsz = find_frame_size(src + ip, srcSize - ip, magicless);
         if (iserr(fsz)) {
             // let the walk of this (last) frame produce the precise error in decode order
             uint32_t const code = zstdgpu_getErrorCode(fsz);
             if (code == E_prefix_unknown && more1) { tailErr = mkerr(E_srcSize_wrong); break; }   // :917-918
             ins.push_back({ip, srcSize - ip, 0, 0});
-            known.push_back(zstdgpu_getFrameContentSize(src + ip, srcSize - ip));
+            known.push_back(frame_content_size(src + ip, srcSize - ip, magicless));
             ip = srcSize;
             break;
         }
         ins.push_back({ip, fsz, 0, 0});
-        known.push_back(zstdgpu_getFrameContentSize(src + ip, fsz));
+        known.push_back(frame_content_size(src + ip, fsz, magicless));
         ip += fsz;
         more1 = true;
     }
@@ -924,7 +964,7 @@ size_t decompress_multi(zstdgpu_ctx* ctx, void* dst, size_t dstCapacity, const v
 
 extern "C" size_t zstdgpu_decompressDCtx(zstdgpu_ctx* ctx, void* dst, size_t dstCapacity, const void* src, size_t srcSize)
 {
-    return decompress_multi(ctx, dst, dstCapacity, src, srcSize, nullptr);
+    return decompress_multi(ctx, dst, dstCapacity, src, srcSize, ctx ? ctx->refDDict : nullptr);   // ZSTD_getDDict (:951-969)
 }
 extern "C" size_t zstdgpu_decompress_usingDDict(zstdgpu_ctx* ctx, void* dst, size_t dstCapacity, const void* src, size_t srcSize, const zstdgpu_ddict* ddict)
 {
@@ -947,11 +987,12 @@ extern "C" size_t zstdgpu_decompress_usingDict(zstdgpu_ctx* ctx, void* dst, size
 // ZSTD_findFrameSizeInfo, :566-639), decodes it, and hands the output over as room is given.  Results are the
 // reference's: the same bytes, 0 returned when a frame has been decoded and flushed completely, a positive hint while
 // more input or more room is needed, the same error codes.
+// In the reference the stream *is* the decoding context (ZSTD_DStream = ZSTD_DCtx): its dictionary and parameters are
+// the context's, so they live in zstdgpu_ctx here too.
 struct zstdgpu_dstream {
     zstdgpu_ctx* ctx = nullptr;
-    const zstdgpu_ddict* ddict = nullptr;
     std::vector<uint8_t> in, out;
-    size_t want = 5;          // bytes of `in` needed before the next decision (ZSTD_FRAMEHEADERSIZE_PREFIX to begin with)
+    size_t want = 5;          // bytes of `in` needed before the next decision (ZSTD_startingInputLength to begin with)
     size_t cursor = 0;        // offset of the next block header in `in` (0: frame header not seen yet)
     size_t blocks = 0;        // blocks seen
     bool checksum = false, skippable = false, lastSeen = false;
@@ -959,7 +1000,9 @@ struct zstdgpu_dstream {
     size_t outPos = 0;
     bool flushing = false;
     size_t error = 0;         // sticky until the stream is reset
-    void reset() { in.clear(); out.clear(); want = 5; cursor = 0; blocks = 0; checksum = skippable = lastSeen = false;
+    zstdgpu_outBuffer expected{nullptr, 0, 0};   // ZSTD_d_stableOutBuffer: the output buffer as the last call left it
+    bool busy() const { return !in.empty() || flushing; }      // streamStage <> zdss_init
+    void reset() { in.clear(); out.clear(); want = ctx->format ? 1 : 5; cursor = 0; blocks = 0; checksum = skippable = lastSeen = false;
                    contentSize = ZSTDGPU_CONTENTSIZE_UNKNOWN; windowSize = 0; outPos = 0; flushing = false; error = 0; }
 };
 
@@ -967,15 +1010,87 @@ extern "C" zstdgpu_dstream* zstdgpu_createDStream(zstdgpu_ctx* ctx)
 {
     if (!ctx) return nullptr;
     zstdgpu_dstream* z = new (std::nothrow) zstdgpu_dstream;
-    if (z) z->ctx = ctx;
+    if (z) { z->ctx = ctx; z->reset(); ctx->streams.push_back(z); }
     return z;
 }
-extern "C" void zstdgpu_freeDStream(zstdgpu_dstream* z) { delete z; }
-// ZSTD_initDStream / ZSTD_initDStream_usingDDict (:1605-1628): start a new stream; returns the first input size hint
-extern "C" size_t zstdgpu_initDStream(zstdgpu_dstream* z) { if (!z) return mkerr(E_generic); z->reset(); z->ddict = nullptr; return 5; }
-extern "C" size_t zstdgpu_initDStream_usingDDict(zstdgpu_dstream* z, const zstdgpu_ddict* ddict) { if (!z) return mkerr(E_generic); z->reset(); z->ddict = ddict; return 5; }
+extern "C" void zstdgpu_freeDStream(zstdgpu_dstream* z)
+{
+    if (!z) return;
+    auto& v = z->ctx->streams;
+    v.erase(std::remove(v.begin(), v.end(), z), v.end());
+    delete z;
+}
+// ZSTD_initDStream / ZSTD_initDStream_usingDDict (:1605-1628): start a new stream (session reset + ZSTD_DCtx_refDDict);
+// returns the first input size hint (ZSTD_startingInputLength of the context's format)
+extern "C" size_t zstdgpu_initDStream(zstdgpu_dstream* z) { if (!z) return mkerr(E_generic); z->reset(); z->ctx->refDDict = nullptr; return z->want; }
+extern "C" size_t zstdgpu_initDStream_usingDDict(zstdgpu_dstream* z, const zstdgpu_ddict* ddict) { if (!z) return mkerr(E_generic); z->reset(); z->ctx->refDDict = ddict; return z->want; }
 // ZSTD_resetDStream (:1630-1637): forget a half-read frame, keep the dictionary
-extern "C" size_t zstdgpu_resetDStream(zstdgpu_dstream* z) { if (!z) return mkerr(E_generic); z->reset(); return 5; }
+extern "C" size_t zstdgpu_resetDStream(zstdgpu_dstream* z) { if (!z) return mkerr(E_generic); z->reset(); return z->want; }
+
+// ---- decoder parameters (zstd_decompressf.pas:1641-1826)
+extern "C" zstdgpu_bounds zstdgpu_dParam_getBounds(zstdgpu_dParameter p)       // ZSTD_dParam_getBounds :1680-1715
+{
+    zstdgpu_bounds b{0, 0, 0};
+    switch ((int)p) {
+        case ZSTDGPU_d_windowLogMax: b.lowerBound = 10; b.upperBound = (int)kWindowLogMax; return b;   // ZSTD_WINDOWLOG_ABSOLUTEMIN .. ZSTD_WINDOWLOG_MAX
+        case ZSTDGPU_d_format: b.lowerBound = 0; b.upperBound = 1; return b;
+        case ZSTDGPU_d_stableOutBuffer: b.lowerBound = 0; b.upperBound = 1; return b;
+        case ZSTDGPU_d_forceIgnoreChecksum: b.lowerBound = 0; b.upperBound = 1; return b;
+        default: break;
+    }
+    b.error = mkerr(E_parameter_unsupported);
+    return b;
+}
+namespace {
+bool any_stream_busy(const zstdgpu_ctx* ctx) { for (auto* z : ctx->streams) if (z->busy()) return true; return false; }
+}  // namespace
+extern "C" size_t zstdgpu_DCtx_setParameter(zstdgpu_ctx* ctx, zstdgpu_dParameter p, int value)   // ZSTD_DCtx_setParameter :1763-1807
+{
+    if (!ctx) return mkerr(E_generic);
+    if (any_stream_busy(ctx)) return mkerr(E_stage_wrong);
+    zstdgpu_bounds const b = zstdgpu_dParam_getBounds(p);
+    if (iserr(b.error)) return b.error;
+    if ((int)p == ZSTDGPU_d_windowLogMax && value == 0) value = 27;     // ZSTD_WINDOWLOG_LIMIT_DEFAULT
+    if (value < b.lowerBound || value > b.upperBound) return mkerr(E_parameter_outOfBound);
+    switch ((int)p) {
+        case ZSTDGPU_d_windowLogMax: ctx->maxWindowSize = 1ull << value; break;
+        case ZSTDGPU_d_format: ctx->format = (uint32_t)value; for (auto* z : ctx->streams) z->reset(); break;
+        case ZSTDGPU_d_stableOutBuffer: ctx->stableOut = (uint32_t)value; break;
+        default: ctx->ignoreChecksum = (uint32_t)value; break;
+    }
+    return 0;
+}
+extern "C" size_t zstdgpu_DCtx_getParameter(zstdgpu_ctx* ctx, zstdgpu_dParameter p, int* value)   // ZSTD_DCtx_getParameter :1735-1761
+{
+    if (!ctx || !value) return mkerr(E_generic);
+    switch ((int)p) {
+        case ZSTDGPU_d_windowLogMax: { int l = 0; while ((ctx->maxWindowSize >> (l + 1)) != 0) l++; *value = l; return 0; }   // ZSTD_highbit32
+        case ZSTDGPU_d_format: *value = (int)ctx->format; return 0;
+        case ZSTDGPU_d_stableOutBuffer: *value = (int)ctx->stableOut; return 0;
+        case ZSTDGPU_d_forceIgnoreChecksum: *value = (int)ctx->ignoreChecksum; return 0;
+        default: return mkerr(E_parameter_unsupported);
+    }
+}
+extern "C" size_t zstdgpu_DCtx_refDDict(zstdgpu_ctx* ctx, const zstdgpu_ddict* ddict)            // ZSTD_DCtx_refDDict :1641-1652
+{
+    if (!ctx) return mkerr(E_generic);
+    if (any_stream_busy(ctx)) return mkerr(E_stage_wrong);
+    ctx->refDDict = ddict;
+    return 0;
+}
+extern "C" size_t zstdgpu_DCtx_reset(zstdgpu_ctx* ctx, zstdgpu_ResetDirective reset)            // ZSTD_DCtx_reset :1809-1826
+{
+    if (!ctx) return mkerr(E_generic);
+    if (reset == ZSTDGPU_reset_session_only || reset == ZSTDGPU_reset_session_and_parameters)
+        for (auto* z : ctx->streams) z->reset();
+    if (reset == ZSTDGPU_reset_parameters || reset == ZSTDGPU_reset_session_and_parameters) {
+        if (any_stream_busy(ctx)) return mkerr(E_stage_wrong);
+        ctx->refDDict = nullptr;
+        ctx->reset_parameters();
+        for (auto* z : ctx->streams) z->reset();
+    }
+    return 0;
+}
 
 extern "C" size_t zstdgpu_decompressStream(zstdgpu_dstream* z, zstdgpu_outBuffer* output, zstdgpu_inBuffer* input)
 {
@@ -984,8 +1099,17 @@ extern "C" size_t zstdgpu_decompressStream(zstdgpu_dstream* z, zstdgpu_outBuffer
     if (output->pos > output->size) return mkerr(E_dstSize_tooSmall);
     if (z->error) return z->error;
     auto fail = [&](uint32_t code) { z->error = mkerr(code); return z->error; };
+    bool const stable = z->ctx->stableOut != 0, magicless = z->ctx->format != 0;
+    // ZSTD_checkOutBuffer (:1913-1928): in stable mode the caller must hand the same buffer back once a frame has begun
+    if (stable && z->busy() && (z->expected.dst != output->dst || z->expected.size != output->size || z->expected.pos != output->pos))
+        return fail(E_dstBuffer_wrong);
+    struct Remember { zstdgpu_dstream* z; zstdgpu_outBuffer* o; ~Remember() { z->expected = *o; } } remember{z, output};
+    bool const fresh = !z->busy();            // this call starts at a frame boundary
+    size_t const startPos = input->pos;
     for (;;) {
         if (z->flushing) {
+            // stable mode decodes straight into the caller's buffer, which must hold what is left of the frame (:1941-1951)
+            if (stable && z->out.size() - z->outPos > output->size - output->pos) return fail(E_dstSize_tooSmall);
             size_t const n = std::min(z->out.size() - z->outPos, output->size - output->pos);
             if (n) memcpy((uint8_t*)output->dst + output->pos, z->out.data() + z->outPos, n);
             output->pos += n; z->outPos += n;
@@ -1003,20 +1127,25 @@ extern "C" size_t zstdgpu_decompressStream(zstdgpu_dstream* z, zstdgpu_outBuffer
         const uint8_t* const p = z->in.data();
         if (z->cursor == 0 && !z->skippable) {
             // frame start: magic, then the whole frame header
-            if (z->in.size() >= 4 && (rd32(p) & kMagicSkipMask) == kMagicSkipStart) {
+            if (!magicless && z->in.size() >= 4 && (rd32(p) & kMagicSkipMask) == kMagicSkipStart) {   // :301-318
                 if (z->in.size() < 8) { z->want = 8; continue; }
                 uint32_t const sz = rd32(p + 4);
                 if ((uint32_t)(sz + 8) < sz) return fail(E_frameParameter_unsupported);
                 z->skippable = true; z->want = (size_t)8 + sz;
                 continue;
             }
-            if (z->in.size() >= 4 && rd32(p) != kMagic) return fail(E_prefix_unknown);
-            size_t const fhsize = frame_header_size(p, z->in.size());
+            if (!magicless && z->in.size() >= 4 && rd32(p) != kMagic) return fail(E_prefix_unknown);
+            size_t const fhsize = frame_header_size(p, z->in.size(), magicless);
             if (z->in.size() < fhsize) { z->want = fhsize; continue; }
             FrameHeader fh;
-            size_t const r = get_frame_header(fh, p, z->in.size());
+            size_t const r = get_frame_header(fh, p, z->in.size(), magicless);
             if (iserr(r)) return fail((uint32_t)(0 - r));
-            if (fh.windowSize > ((1ull << 27) + 1)) return fail(E_frameParameter_windowTooLarge);     // ZSTD_MAXWINDOWSIZE_DEFAULT (:51, :2166)
+            // The reference decodes a frame in one pass, without its streaming window buffer and so without the window
+            // limit, when the frame is whole in this call's input, its content size is known and the output has room
+            // for it (:2111-2129); otherwise ZSTD_d_windowLogMax applies (:2166).
+            bool const onePass = fresh && fh.contentSize != ZSTDGPU_CONTENTSIZE_UNKNOWN && output->size - output->pos >= fh.contentSize &&
+                                 !iserr(find_frame_size((const uint8_t*)input->src + startPos, input->size - startPos, false));
+            if (!onePass && fh.windowSize > z->ctx->maxWindowSize) return fail(E_frameParameter_windowTooLarge);
             z->checksum = fh.checksumFlag != 0; z->contentSize = fh.contentSize; z->windowSize = fh.windowSize;
             z->cursor = fhsize; z->want = fhsize + 3;
             continue;
@@ -1042,7 +1171,7 @@ extern "C" size_t zstdgpu_decompressStream(zstdgpu_dstream* z, zstdgpu_outBuffer
             uint64_t const bound = z->contentSize != ZSTDGPU_CONTENTSIZE_UNKNOWN ? z->contentSize : (uint64_t)z->blocks * kBlockSizeMax;
             if (bound > 0x7FFFFFFEull) return fail(E_memory_allocation);
             z->out.resize((size_t)bound);
-            size_t const r = decompress_multi(z->ctx, z->out.data(), z->out.size(), p, z->in.size(), z->ddict);
+            size_t const r = decompress_multi(z->ctx, z->out.data(), z->out.size(), p, z->in.size(), z->ctx->refDDict);
             if (iserr(r)) { z->error = r; return r; }
             z->out.resize(r);
             z->outPos = 0; z->flushing = true;

@@ -8,9 +8,14 @@ namespace zg {
 enum : uint32_t {
     E_none = 0, E_generic = 1, E_prefix_unknown = 10, E_frameParameter_unsupported = 14,
     E_frameParameter_windowTooLarge = 16, E_corruption = 20, E_checksum_wrong = 22,
-    E_dictionary_corrupted = 30, E_dictionary_wrong = 32, E_memory_allocation = 64,
-    E_dstSize_tooSmall = 70, E_srcSize_wrong = 72, E_maxCode = 120
+    E_dictionary_corrupted = 30, E_dictionary_wrong = 32, E_parameter_unsupported = 40, E_parameter_outOfBound = 42,
+    E_stage_wrong = 60, E_memory_allocation = 64,
+    E_dstSize_tooSmall = 70, E_srcSize_wrong = 72, E_dstBuffer_wrong = 104, E_maxCode = 120
 };
+
+// options of the frame walk (host and device builders): a dictionary is attached; ZSTD_f_zstd1_magicless
+// (zstd.pas:416-417); ZSTD_d_ignoreChecksum (the trailer is skipped, not compared: zstd_decompressf.pas:815-828)
+enum : uint32_t { kOptDict = 1, kOptMagicless = 2, kOptIgnoreChecksum = 4 };
 
 enum : int32_t { SRC_DICT = -1, SRC_NONE = -2 };
 enum : uint8_t { BT_RAW = 0, BT_RLE = 1, BT_COMPRESSED = 2, BT_STOP = 3 };   // BT_STOP: walk ended here with an error
@@ -117,9 +122,9 @@ struct FrameIn { uint64_t srcOff, srcSize, dstOff, dstCapacity; };
 // descriptor builder on the device (descriptors.hip).  totals: [0] block slots, [1] literal buffer bytes,
 // [2] split-decode scratch bytes, [3] sequence records, [4] literal jobs, [5] sequence jobs, [6] source bytes of the
 // frames without a header error (8 entries)
-void launch_scan_frames(const uint8_t* src, uint64_t srcBytes, const FrameIn* in, uint32_t nFrames, uint32_t batchDictID, uint32_t haveDict,
+void launch_scan_frames(const uint8_t* src, uint64_t srcBytes, const FrameIn* in, uint32_t nFrames, uint32_t batchDictID, uint32_t opts,
                         DevFrame* frames, uint32_t* slots, uint64_t* totals, void* stream);
-void launch_fill_blocks(const uint8_t* src, uint64_t srcBytes, const FrameIn* in, uint32_t nFrames, uint32_t batchDictID, uint32_t haveDict,
+void launch_fill_blocks(const uint8_t* src, uint64_t srcBytes, const FrameIn* in, uint32_t nFrames, uint32_t batchDictID, uint32_t opts,
                         uint32_t dictEntropy, const DevFrame* frames, DevBlock* blocks, uint8_t* flags, uint32_t nBlocks,
                         uint32_t* litJobs, uint32_t* seqJobs, uint64_t* totals, void* stream);
 
