@@ -2356,10 +2356,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
             int64_t const absS = pl.absS;
             int64_t const batchAbs = (int64_t)(bo + base0);
             uint32_t const slowS = (have && !fastS && !nearS) ? ml : 0;
+#ifdef ZG_STAMPS
+            unsigned long long const slowMask = __ballot(slowS != 0);
+#endif
             const uint8_t* const matSrc = absS >= 0 ? fdst + absS : dictEnd + absS;
 #ifdef ZG_STAMPS
             uint64_t const x1 = __builtin_readcyclecounter();
-            uint64_t x2 = x1, x3 = x1, x4 = x1;
+            uint64_t x2 = x1, x3 = x1, x4 = x1, xa = x1, xb = x1;
 #endif
             // ---- all global loads of a batch assembled in LDS: one coalesced literal load, one or two 16-byte loads per
             // plain match, single bytes for source bytes before the batch of the other matches
@@ -2424,6 +2427,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
                 lds_copy_runs(outB + start, litStage + (litRle ? 0u : lstart - lit0), ll,
                               outB + start + ll, nearS ? outB + start + ll - off : matStage + 32 * lane, nearS ? ml : fastLen);
                 if (gdst != 0xFFFFFFFFu) outB[gdst] = gv;
+#ifdef ZG_STAMPS
+                xa = __builtin_readcyclecounter();
+#endif
                 // ---- the other matches, one after the other in sequence order: everything before a match is in place
                 // when its turn comes.  Byte j repeats pattern byte j mod offset; the pattern is the `offset` bytes before
                 // the match, of which those before the batch were fetched to the head of the match itself.
@@ -2444,6 +2450,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
                         }
                     }
                 }
+#ifdef ZG_STAMPS
+                xb = __builtin_readcyclecounter();
+#endif
                 lds_sync();
                 // ---- the batch's output, contiguous: 16 bytes per lane, then the last bytes one per lane
                 {
@@ -2478,7 +2487,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
             if (p.dbg && lane == 0) {
                 uint64_t const x5 = __builtin_readcyclecounter();
                 uint64_t* const g = p.dbg + 8 * fi;
-                g[0] += x1 - x0; g[1] += x2 - x1; g[2] += x3 - x2; g[3] += x4 - x3; g[4] += x5 - x4; g[5] += 1; g[6] += __builtin_popcountll(__ballot(slowS != 0)); g[7] += staged ? 1 : 0;
+                g[0] += x1 - x0; g[1] += x3 - x1; g[2] += xa - x3; g[3] += xb - xa; g[4] += x4 - xb; g[5] += 1; g[6] += uni((uint32_t)__builtin_popcountll(slowMask)); g[7] += x5 - x4;
             }
 #endif
             pl = plN;

@@ -739,7 +739,7 @@ extern "C" size_t zstdgpu_batch_decode(zstdgpu_batch* B, const void* devSrc, voi
         }
         double t[8] = {0}; size_t n = 0;
         for (size_t i = 0; i < p.nFrames; i++) if (h[8 * i + 5]) { for (int j = 0; j < 8; j++) t[j] += h[8 * i + j]; n++; }
-        if (n) fprintf(stderr, "[stamps] k_execute per frame: setup %.0f  load-issue %.0f  load-wait %.0f  assemble+store %.0f  rest %.0f ticks; %.0f batches, %.0f extra passes, %.0f staged\n",
+        if (n) fprintf(stderr, "[stamps] k_execute per frame: setup %.0f  load issue + plan + wait + stage writes %.0f  runs %.0f  dependent matches %.0f  store %.0f ticks; %.0f batches, %.0f dependent matches, rest %.0f ticks\n",
                        t[0] / n, t[1] / n, t[2] / n, t[3] / n, t[4] / n, t[5] / n, t[6] / n, t[7] / n);
     }
 #endif
