@@ -47,6 +47,21 @@ void         zstdgpu_destroy(zstdgpu_ctx* ctx);
  * ZSTD_getDictID_fromDict (:1455), ZSTD_getDictID_fromFrame (:1473). */
 unsigned long long zstdgpu_getFrameContentSize(const void* src, size_t srcSize);
 size_t             zstdgpu_findFrameCompressedSize(const void* src, size_t srcSize);
+unsigned           zstdgpu_isFrame(const void* src, size_t srcSize);                      /* ZSTD_isFrame :223 */
+size_t             zstdgpu_frameHeaderSize(const void* src, size_t srcSize);              /* ZSTD_frameHeaderSize :269 */
+typedef struct {                                  /* ZSTD_frameHeader, common/zstd.pas:489-497 */
+    unsigned long long frameContentSize;          /* ZSTDGPU_CONTENTSIZE_UNKNOWN when the header has none; skippable: its size field */
+    unsigned long long windowSize;
+    unsigned blockSizeMax;
+    unsigned frameType;                           /* 0 ZSTD_frame, 1 ZSTD_skippableFrame */
+    unsigned headerSize;
+    unsigned dictID;
+    unsigned checksumFlag;
+} zstdgpu_frameHeader;
+size_t             zstdgpu_getFrameHeader(zstdgpu_frameHeader* zfh, const void* src, size_t srcSize);   /* ZSTD_getFrameHeader :403; 0, bytes wanted, or error */
+unsigned long long zstdgpu_getDecompressedSize(const void* src, size_t srcSize);          /* ZSTD_getDecompressedSize :525 */
+unsigned long long zstdgpu_findDecompressedSize(const void* src, size_t srcSize);         /* ZSTD_findDecompressedSize :466 (all frames) */
+unsigned long long zstdgpu_decompressBound(const void* src, size_t srcSize);              /* ZSTD_decompressBound :660 (all frames) */
 unsigned           zstdgpu_getDictID_fromDict(const void* dict, size_t dictSize);
 unsigned           zstdgpu_getDictID_fromFrame(const void* src, size_t srcSize);
 

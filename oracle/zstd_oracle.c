@@ -1199,7 +1199,9 @@ unsigned oracle_getErrorCode(size_t code) { return isErr(code) ? (unsigned)((siz
 U64 oracle_getFrameContentSize(const void* src, size_t srcSize)
 {
     FrameHeader zfh;
-    if (srcSize >= 4 && (rdLE32((const BYTE*)src) & ZSTD_MAGIC_SKIPPABLE_MASK) == ZSTD_MAGIC_SKIPPABLE_START) return 0;
+    /* skippable frame (:303-313 through ZSTD_getFrameHeader): needs its 8-byte header, content size 0 */
+    if (srcSize >= 5 && (rdLE32((const BYTE*)src) & ZSTD_MAGIC_SKIPPABLE_MASK) == ZSTD_MAGIC_SKIPPABLE_START)
+        return srcSize >= 8 ? 0 : ZSTD_CONTENTSIZE_UNKNOWN - 1;
     if (ZSTD_getFrameHeader(&zfh, (const BYTE*)src, srcSize, 0) != 0) return ZSTD_CONTENTSIZE_UNKNOWN - 1;
     return zfh.frameContentSize;
 }
@@ -1215,6 +1217,7 @@ size_t oracle_findFrameCompressedSize(const void* srcv, size_t srcSize)
         if (skippableSize > srcSize) return ERR(srcSize_wrong);
         return skippableSize;
     }
+    if (srcSize >= 5 && (rdLE32(src) & ZSTD_MAGIC_SKIPPABLE_MASK) == ZSTD_MAGIC_SKIPPABLE_START) return ERR(srcSize_wrong);   /* half a skippable header: ZSTD_getFrameHeader wants 8 bytes (:303-308, :599) */
     {   const BYTE* ip = src;
         size_t remainingSize = srcSize;
         FrameHeader zfh;

@@ -75,3 +75,49 @@ def test_build_descriptors_flags_host_errors():
     assert fds[1].hostError == 10                     # bad magic
     assert fds[2].hostError == 0 and bds[fds[2].firstBlock + fds[2].nBlocks - 1].blockType == 3   # walk stops inside the frame
     assert fds[3].hostError == 72                     # bytes after the frame
+
+
+# ------------------------------------------------------------------ header / size queries against libzstd's answers
+import json  # noqa: E402
+
+with open(os.path.join(ROOT, "tests", "golden", "queries.json")) as _f:
+    QUERIES = json.load(_f)
+
+
+def _check_queries(data: bytes, q, tag):
+    def size_or_error(call):
+        try:
+            return {"value": call()}
+        except api.ZstdError as ex:
+            return {"error": ex.code}
+
+    assert api.ZSTD_isFrame(data) == q["isFrame"], tag
+    assert size_or_error(lambda: api.ZSTD_frameHeaderSize(data)) == q["frameHeaderSize"], tag
+    try:
+        r, hdr = api.ZSTD_getFrameHeader(data)
+        assert {"value": r} == q["getFrameHeader"], tag
+        if r == 0:
+            assert hdr == q["header"], tag
+    except api.ZstdError as ex:
+        assert {"error": ex.code} == q["getFrameHeader"], tag
+    assert api.ZSTD_getFrameContentSize(data) == q["getFrameContentSize"], tag
+    assert api.ZSTD_getDecompressedSize(data) == q["getDecompressedSize"], tag
+    assert size_or_error(lambda: api.ZSTD_findFrameCompressedSize(data)) == q["findFrameCompressedSize"], tag
+    assert api.ZSTD_findDecompressedSize(data) == q["findDecompressedSize"], tag
+    assert api.ZSTD_decompressBound(data) == q["decompressBound"], tag
+
+
+def test_queries_match_libzstd_on_every_fixture():
+    """ZSTD_isFrame, ZSTD_frameHeaderSize, ZSTD_getFrameHeader, ZSTD_getFrameContentSize, ZSTD_getDecompressedSize,
+    ZSTD_findFrameCompressedSize, ZSTD_findDecompressedSize, ZSTD_decompressBound: libzstd 1.4.8's recorded answers."""
+    assert len(QUERIES["whole"]) == len(FRAMES)
+    for e in FRAMES:
+        _check_queries(read_frame(e), QUERIES["whole"][e["name"]], e["name"])
+
+
+def test_queries_match_libzstd_on_prefixes():
+    """The same on the first 0..23 bytes of some frames (bytes-wanted results, half-read skippable headers)."""
+    for name, cuts in QUERIES["prefixes"].items():
+        data = read_frame(next(x for x in FRAMES if x["name"] == name))
+        for cut, q in cuts.items():
+            _check_queries(data[:int(cut)], q, f"{name}[:{cut}]")

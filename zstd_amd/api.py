@@ -59,6 +59,8 @@ EXPORTS = (
     "zstdgpu_isError", "zstdgpu_getErrorCode", "zstdgpu_getErrorName", "zstdgpu_versionNumber",
     "zstdgpu_create", "zstdgpu_destroy",
     "zstdgpu_getFrameContentSize", "zstdgpu_findFrameCompressedSize", "zstdgpu_getDictID_fromDict", "zstdgpu_getDictID_fromFrame",
+    "zstdgpu_isFrame", "zstdgpu_frameHeaderSize", "zstdgpu_getFrameHeader", "zstdgpu_getDecompressedSize", "zstdgpu_findDecompressedSize",
+    "zstdgpu_decompressBound",
     "zstdgpu_createDDict", "zstdgpu_freeDDict",
     "zstdgpu_decompress", "zstdgpu_decompressDCtx", "zstdgpu_decompress_usingDict", "zstdgpu_decompress_usingDDict",
     "zstdgpu_buildDescriptors", "zstdgpu_batch_create", "zstdgpu_batch_create_from_frames", "zstdgpu_batch_create_on_device",
@@ -70,6 +72,12 @@ EXPORTS = (
     "zstdgpu_batch_scratchBytes", "zstdgpu_batch_set_profiling", "zstdgpu_batch_stage_ms", "zstdgpu_stage_kernel_name",
     "zstdgpu_xxh64Batch", "zstdgpu_batch_blockInfo", "zstdgpu_batch_copyLiterals", "zstdgpu_batch_copySequences",
 )
+
+
+class FrameHeader(ctypes.Structure):
+    """zstdgpu_frameHeader (ZSTD_frameHeader)."""
+    _fields_ = [("frameContentSize", ctypes.c_ulonglong), ("windowSize", ctypes.c_ulonglong), ("blockSizeMax", ctypes.c_uint),
+                ("frameType", ctypes.c_uint), ("headerSize", ctypes.c_uint), ("dictID", ctypes.c_uint), ("checksumFlag", ctypes.c_uint)]
 
 
 class Bounds(ctypes.Structure):
@@ -107,6 +115,12 @@ def lib():
     proto("zstdgpu_destroy", None, vp)
     proto("zstdgpu_getFrameContentSize", ctypes.c_ulonglong, vp, sz)
     proto("zstdgpu_findFrameCompressedSize", sz, vp, sz)
+    proto("zstdgpu_isFrame", ctypes.c_uint, vp, sz)
+    proto("zstdgpu_frameHeaderSize", sz, vp, sz)
+    proto("zstdgpu_getFrameHeader", sz, P(FrameHeader), vp, sz)
+    proto("zstdgpu_getDecompressedSize", ctypes.c_ulonglong, vp, sz)
+    proto("zstdgpu_findDecompressedSize", ctypes.c_ulonglong, vp, sz)
+    proto("zstdgpu_decompressBound", ctypes.c_ulonglong, vp, sz)
     proto("zstdgpu_getDictID_fromDict", ctypes.c_uint, vp, sz)
     proto("zstdgpu_getDictID_fromFrame", ctypes.c_uint, vp, sz)
     proto("zstdgpu_createDDict", vp, vp, vp, sz)
@@ -170,6 +184,33 @@ def ZSTD_getFrameContentSize(src: bytes) -> int:
 
 def ZSTD_findFrameCompressedSize(src: bytes) -> int:
     return _check(lib().zstdgpu_findFrameCompressedSize(src, len(src)))
+
+
+def ZSTD_isFrame(src: bytes) -> int:
+    return lib().zstdgpu_isFrame(src, len(src))
+
+
+def ZSTD_frameHeaderSize(src: bytes) -> int:
+    return _check(lib().zstdgpu_frameHeaderSize(src, len(src)))
+
+
+def ZSTD_getFrameHeader(src: bytes):
+    """Returns (0, dict of the header fields), or (bytes wanted, None); raises ZstdError for an invalid header."""
+    h = FrameHeader()
+    r = _check(lib().zstdgpu_getFrameHeader(ctypes.byref(h), src, len(src)))
+    return (0, {f: int(getattr(h, f)) for f, _ in FrameHeader._fields_}) if r == 0 else (r, None)
+
+
+def ZSTD_getDecompressedSize(src: bytes) -> int:
+    return lib().zstdgpu_getDecompressedSize(src, len(src))
+
+
+def ZSTD_findDecompressedSize(src: bytes) -> int:
+    return lib().zstdgpu_findDecompressedSize(src, len(src))
+
+
+def ZSTD_decompressBound(src: bytes) -> int:
+    return lib().zstdgpu_decompressBound(src, len(src))
 
 
 def ZSTD_getDictID_fromDict(d: bytes) -> int:

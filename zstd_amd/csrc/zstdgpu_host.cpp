@@ -368,7 +368,9 @@ extern "C" void zstdgpu_destroy(zstdgpu_ctx* ctx)
 namespace {
 unsigned long long frame_content_size(const uint8_t* s, size_t srcSize, bool magicless)
 {
-    if (srcSize >= 4 && (rd32(s) & kMagicSkipMask) == kMagicSkipStart) return 0;   // :374-385 (skippable: content size 0)
+    // ZSTD_getFrameContentSize (:414-431) over ZSTD_getFrameHeader_advanced (:296-318): a skippable frame needs its
+    // 8-byte header to be there and has content size 0
+    if (!magicless && srcSize >= 5 && (rd32(s) & kMagicSkipMask) == kMagicSkipStart) return srcSize >= 8 ? 0 : ZSTDGPU_CONTENTSIZE_ERROR;
     FrameHeader h;
     if (get_frame_header(h, s, srcSize, magicless) != 0) return ZSTDGPU_CONTENTSIZE_ERROR;
     return h.contentSize;
@@ -387,6 +389,7 @@ namespace {
 size_t find_frame_size(const uint8_t* src, size_t srcSize, bool magicless)
 {
     if (srcSize >= 8 && (rd32(src) & kMagicSkipMask) == kMagicSkipStart) return skippable_size(src, srcSize);
+    if (!magicless && srcSize >= 5 && (rd32(src) & kMagicSkipMask) == kMagicSkipStart) return mkerr(E_srcSize_wrong);   // half a skippable header (:303-308, :599)
     FrameHeader h;
     size_t const r = get_frame_header(h, src, srcSize, magicless);
     if (iserr(r)) return r;
@@ -406,6 +409,104 @@ size_t find_frame_size(const uint8_t* src, size_t srcSize, bool magicless)
     return ip;
 }
 }  // namespace
+// ZSTD_isFrame (zstd_decompressf.pas:223-239)
+extern "C" unsigned zstdgpu_isFrame(const void* src, size_t srcSize)
+{
+    if (srcSize < 4) return 0;
+    uint32_t const magic = rd32((const uint8_t*)src);
+    return magic == kMagic || (magic & kMagicSkipMask) == kMagicSkipStart;
+}
+// ZSTD_frameHeaderSize (:269-272)
+extern "C" size_t zstdgpu_frameHeaderSize(const void* src, size_t srcSize)
+{
+    return frame_header_size((const uint8_t*)src, srcSize, false);
+}
+// ZSTD_getFrameHeader (:403-406): 0, or the number of bytes wanted, or an error
+extern "C" size_t zstdgpu_getFrameHeader(zstdgpu_frameHeader* zfh, const void* srcv, size_t srcSize)
+{
+    const uint8_t* const src = (const uint8_t*)srcv;
+    if (!zfh) return mkerr(E_generic);
+    memset(zfh, 0, sizeof(*zfh));
+    if (srcSize < 5) return 5;
+    if (!src) return mkerr(E_generic);
+    if ((rd32(src) & kMagicSkipMask) == kMagicSkipStart) {      // :303-313
+        if (srcSize < 8) return 8;
+        zfh->frameContentSize = rd32(src + 4);
+        zfh->frameType = 1;
+        return 0;
+    }
+    FrameHeader h;
+    size_t const r = get_frame_header(h, src, srcSize, false);
+    if (r != 0) return r;
+    zfh->frameContentSize = h.contentSize; zfh->windowSize = h.windowSize;
+    zfh->blockSizeMax = (unsigned)(h.windowSize < kBlockSizeMax ? h.windowSize : kBlockSizeMax);     // :389
+    zfh->frameType = 0; zfh->headerSize = h.headerSize; zfh->dictID = h.dictID; zfh->checksumFlag = h.checksumFlag;
+    return 0;
+}
+// ZSTD_getDecompressedSize (:525-535)
+extern "C" unsigned long long zstdgpu_getDecompressedSize(const void* src, size_t srcSize)
+{
+    unsigned long long const r = zstdgpu_getFrameContentSize(src, srcSize);
+    return r >= ZSTDGPU_CONTENTSIZE_ERROR ? 0 : r;
+}
+// ZSTD_findDecompressedSize (:466-515): sum of the content sizes of all the frames in src
+extern "C" unsigned long long zstdgpu_findDecompressedSize(const void* srcv, size_t srcSize)
+{
+    const uint8_t* src = (const uint8_t*)srcv;
+    unsigned long long total = 0;
+    while (srcSize >= 5) {
+        if ((rd32(src) & kMagicSkipMask) == kMagicSkipStart) {
+            size_t const sk = skippable_size(src, srcSize);
+            if (iserr(sk)) return ZSTDGPU_CONTENTSIZE_ERROR;
+            src += sk; srcSize -= sk;
+            continue;
+        }
+        unsigned long long const r = zstdgpu_getFrameContentSize(src, srcSize);
+        if (r >= ZSTDGPU_CONTENTSIZE_ERROR) return r;
+        if (total + r < total) return ZSTDGPU_CONTENTSIZE_ERROR;
+        total += r;
+        size_t const fsz = find_frame_size(src, srcSize, false);
+        if (iserr(fsz)) return ZSTDGPU_CONTENTSIZE_ERROR;
+        src += fsz; srcSize -= fsz;
+    }
+    if (srcSize) return ZSTDGPU_CONTENTSIZE_ERROR;
+    return total;
+}
+// ZSTD_decompressBound (:660-681) over ZSTD_findFrameSizeInfo (:566-639): content size where the header has it, else
+// blocks x blockSizeMax; skippable frames add nothing
+extern "C" unsigned long long zstdgpu_decompressBound(const void* srcv, size_t srcSize)
+{
+    const uint8_t* src = (const uint8_t*)srcv;
+    unsigned long long bound = 0;
+    while (srcSize > 0) {
+        if (srcSize >= 8 && (rd32(src) & kMagicSkipMask) == kMagicSkipStart) {
+            size_t const sk = skippable_size(src, srcSize);
+            if (iserr(sk)) return ZSTDGPU_CONTENTSIZE_ERROR;
+            src += sk; srcSize -= sk;
+            continue;
+        }
+        FrameHeader h;
+        if (get_frame_header(h, src, srcSize, false) != 0) return ZSTDGPU_CONTENTSIZE_ERROR;
+        size_t ip = h.headerSize, remaining = srcSize - h.headerSize;
+        unsigned long long nbBlocks = 0;
+        for (;;) {
+            if (remaining < 3) return ZSTDGPU_CONTENTSIZE_ERROR;
+            uint32_t const hdr = rd24(src + ip);
+            uint32_t const type = (hdr >> 1) & 3;
+            if (type == 3) return ZSTDGPU_CONTENTSIZE_ERROR;
+            size_t const cSize = type == BT_RLE ? 1 : (hdr >> 3);
+            if (3 + cSize > remaining) return ZSTDGPU_CONTENTSIZE_ERROR;
+            ip += 3 + cSize; remaining -= 3 + cSize;
+            nbBlocks++;
+            if (hdr & 1) break;
+        }
+        if (h.checksumFlag) { if (remaining < 4) return ZSTDGPU_CONTENTSIZE_ERROR; ip += 4; }
+        unsigned long long const blockMax = h.windowSize < kBlockSizeMax ? h.windowSize : kBlockSizeMax;
+        bound += h.contentSize != ZSTDGPU_CONTENTSIZE_UNKNOWN ? h.contentSize : nbBlocks * blockMax;
+        src += ip; srcSize -= ip;
+    }
+    return bound;
+}
 extern "C" unsigned zstdgpu_getDictID_fromDict(const void* dict, size_t dictSize)
 {
     if (dictSize < 8 || rd32((const uint8_t*)dict) != kMagicDict) return 0;
