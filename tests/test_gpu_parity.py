@@ -589,3 +589,23 @@ def test_stable_out_buffer(dctx):
         zs.close()
     finally:
         dctx.reset()
+
+
+# ------------------------------------------------------------------ differential fuzz (tools/fuzz.py), a short run
+@pytest.mark.parametrize("corrupt", [False, True], ids=["valid", "damaged"])
+def test_fuzz_short_run(dctx, corrupt):
+    """Seeded inputs of nine shapes, sizes 1 B .. 300 KB, levels -5 .. 19, random window sizes and flags, compressed with
+    the system libzstd: decoded in one batch through both descriptor walks (and, damaged, frame by frame through the
+    one-shot entry point) -- bytes by XXH64 against the plain input, verdicts against the oracle."""
+    from zstd_amd import corpus
+    if not corpus.SystemZstd.available():
+        pytest.skip("no system libzstd to compress with")
+    import argparse
+    import importlib.util
+    import os
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("zg_fuzz", os.path.join(ROOT, "tools", "fuzz.py"))
+    fuzz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz)
+    args = argparse.Namespace(rounds=2, frames=300, seed=5 if corrupt else 4, max_kb=300, corrupt=corrupt)
+    assert fuzz.run(args, dctx) == 0
