@@ -592,8 +592,9 @@ def test_stable_out_buffer(dctx):
 
 
 # ------------------------------------------------------------------ differential fuzz (tools/fuzz.py), a short run
-@pytest.mark.parametrize("corrupt", [False, True], ids=["valid", "damaged"])
-def test_fuzz_short_run(dctx, corrupt):
+@pytest.mark.parametrize("corrupt,with_dict", [(False, False), (True, False), (False, True), (True, True)],
+                         ids=["valid", "damaged", "dictionary", "dictionary-damaged"])
+def test_fuzz_short_run(dctx, corrupt, with_dict):
     """Seeded inputs of nine shapes, sizes 1 B .. 300 KB, levels -5 .. 19, random window sizes and flags, compressed with
     the system libzstd: decoded in one batch through both descriptor walks (and, damaged, frame by frame through the
     one-shot entry point) -- bytes by XXH64 against the plain input, verdicts against the oracle."""
@@ -607,5 +608,5 @@ def test_fuzz_short_run(dctx, corrupt):
     spec = importlib.util.spec_from_file_location("zg_fuzz", os.path.join(ROOT, "tools", "fuzz.py"))
     fuzz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fuzz)
-    args = argparse.Namespace(rounds=2, frames=300, seed=5 if corrupt else 4, max_kb=300, corrupt=corrupt)
+    args = argparse.Namespace(rounds=2, frames=300, seed=4 + int(corrupt) + 2 * int(with_dict), max_kb=300, corrupt=corrupt, dict=with_dict)
     assert fuzz.run(args, dctx) == 0

@@ -78,11 +78,23 @@ def run(args, dctx=None) -> int:
     assert torch.cuda.is_available()
     dctx = dctx or api.DCtx(0)
     tls = {}
+    use_dict = getattr(args, "dict", False)
+    dictionary, ddict = None, None
+    if use_dict:
+        # a dictionary trained on text and record samples; with --dict every frame is compressed with it (some without
+        # a dictionary ID in the header) and sizes stay small, where a dictionary matters
+        zt = corpus.SystemZstd()
+        rs = np.random.default_rng(args.seed)
+        samples = [corpus.mixed(int(rs.integers(0, 1 << 30)), int(rs.integers(500, 6000))) for _ in range(1500)]
+        dictionary = zt.train_dictionary(samples, int(rs.choice([8192, 30000, 112640])))
+        ddict = api.DDict(dctx, dictionary)
 
     def compress(job):
         import threading
         z = tls.setdefault(threading.get_ident(), corpus.SystemZstd())
         plain, level, ck, cs, wlog = job
+        if use_dict:
+            return z.compress(plain, level, checksum=ck, content_size=cs, window_log=wlog, dictionary=dictionary, dict_id=len(plain) % 7 != 0)
         return z.compress(plain, level, checksum=ck, content_size=cs, window_log=wlog)
 
     bad = 0
@@ -91,7 +103,7 @@ def run(args, dctx=None) -> int:
         t0 = time.time()
         jobs = []
         for i in range(args.frames):
-            n = int(np.exp(rng.uniform(0, np.log(args.max_kb * 1024))))
+            n = int(np.exp(rng.uniform(0, np.log((16 if use_dict else args.max_kb) * 1024))))
             if rng.random() < 0.05:
                 n = int(rng.integers(0, 40))
             plain = gen_plain(rng, n)
@@ -118,7 +130,7 @@ def run(args, dctx=None) -> int:
             frames = damaged
 
             def expect(k):
-                out, err = oracle.decompress(frames[k], caps[k])
+                out, err = oracle.decompress(frames[k], caps[k], dictionary)
                 return (oracle.xxh64(out) if not err else 0, err, len(out) if not err else 0)
             with ThreadPoolExecutor(16) as ex:
                 exp = list(ex.map(expect, range(len(frames))))
@@ -130,7 +142,7 @@ def run(args, dctx=None) -> int:
         t1 = time.time()
         digests = []
         for device_walk in (False, True):
-            b = api.Batch(dctx, None, fin, None, dev_src_ptr=d_src.data_ptr(), dev_src_bytes=src.nbytes) if device_walk else api.Batch(dctx, src, fin)
+            b = api.Batch(dctx, None, fin, ddict, dev_src_ptr=d_src.data_ptr(), dev_src_bytes=src.nbytes) if device_walk else api.Batch(dctx, src, fin, ddict)
             digests.append(b.descriptor_digest)
             d_dst = torch.zeros(max(dst_bytes, 1), dtype=torch.uint8, device="cuda")
             b.decode(d_src.data_ptr(), d_dst.data_ptr(), torch.cuda.current_stream().cuda_stream)
@@ -153,7 +165,7 @@ def run(args, dctx=None) -> int:
         if args.corrupt:          # the one-shot entry point, frame by frame: verdict and bytes exactly as the oracle's
             for i in range(len(jobs)):
                 try:
-                    out = api.ZSTD_decompressDCtx(dctx, frames[i], caps[i])
+                    out = api.ZSTD_decompress_usingDDict(dctx, frames[i], caps[i], ddict) if ddict else api.ZSTD_decompressDCtx(dctx, frames[i], caps[i])
                     gerr, gh, gl = 0, oracle.xxh64(out), len(out)
                 except api.ZstdError as ex:
                     gerr, gh, gl = ex.code, 0, 0
@@ -168,6 +180,8 @@ def run(args, dctx=None) -> int:
             bad += 1
             print(f"DIGEST MISMATCH round {r}", flush=True)
         print(f"round {r}: {len(jobs)} frames, {sum(caps) / 1e6:.1f} MB plain, compress {t1 - t0:.1f}s, decode+check {time.time() - t1:.1f}s, bad so far {bad}", flush=True)
+    if ddict:
+        ddict.close()
     return bad
 
 
@@ -178,6 +192,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--max-kb", type=int, default=400)
     ap.add_argument("--corrupt", action="store_true", help="damage every frame (1-3 random bytes) and compare verdicts and bytes with the CPU oracle")
+    ap.add_argument("--dict", action="store_true", help="small frames compressed with a trained dictionary")
     bad = run(ap.parse_args())
     print("FUZZ", "FAILED" if bad else "OK")
     sys.exit(1 if bad else 0)
