@@ -2154,8 +2154,8 @@ __attribute__((noinline)) static __device__ void exec_batch_direct(const uint32_
 }
 
 // Two runs of 0..32 bytes each copied inside LDS (unaligned).  A run is two, possibly overlapping, accesses of one
-// size: 16 bytes at the start and 16 at the end for 16..32, likewise 8 / 4 / 2 for shorter runs, one byte for a run
-// of 1 -- an exact cover with at most two accesses.  The two runs go through each size class together.
+// size: 16 bytes at the start and 16 at the end for 16..32, likewise 8 / 4 for shorter runs, three single bytes for
+// runs of 1..3 -- an exact cover.  The two runs go through each size class together.
 template <typename T>
 DEVI void lds_copy_class(uint8_t* dstA, const uint8_t* srcA, uint32_t lenA, uint8_t* dstB, const uint8_t* srcB, uint32_t lenB, uint32_t lo, uint32_t hi)
 {
@@ -2171,8 +2171,15 @@ DEVI void lds_copy_runs(uint8_t* dstA, const uint8_t* srcA, uint32_t lenA, uint8
     lds_copy_class<uint4>(dstA, srcA, lenA, dstB, srcB, lenB, 16, 33);
     lds_copy_class<uint2>(dstA, srcA, lenA, dstB, srcB, lenB, 8, 16);
     lds_copy_class<uint32_t>(dstA, srcA, lenA, dstB, srcB, lenB, 4, 8);
-    lds_copy_class<uint16_t>(dstA, srcA, lenA, dstB, srcB, lenB, 2, 4);
-    lds_copy_class<uint8_t>(dstA, srcA, lenA, dstB, srcB, lenB, 1, 2);
+    // runs of 1..3 bytes: first, middle and last byte (for 1 and 2 bytes some of them coincide)
+    {
+        bool const inA = lenA >= 1 && lenA < 4, inB = lenB >= 1 && lenB < 4;
+        uint8_t a0 = 0, a1 = 0, a2 = 0, b0 = 0, b1 = 0, b2 = 0;
+        if (inA) { a0 = srcA[0]; a1 = srcA[lenA >> 1]; a2 = srcA[lenA - 1]; }
+        if (inB) { b0 = srcB[0]; b1 = srcB[lenB >> 1]; b2 = srcB[lenB - 1]; }
+        if (inA) { dstA[0] = a0; dstA[lenA >> 1] = a1; dstA[lenA - 1] = a2; }
+        if (inB) { dstB[0] = b0; dstB[lenB >> 1] = b1; dstB[lenB - 1] = b2; }
+    }
 }
 
 // A value known to be the same in every lane, moved to a scalar register.
