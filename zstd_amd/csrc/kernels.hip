@@ -713,7 +713,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
             uint32_t t[2], nDec[2], upTo[2], hdT[2], q[2], ckv[2], rem[2];
             bool met[2], failed[2], prevActive[2];
             uintptr_t wbL[2], pwb[2];
-            uint4 pv[2][6];                 // the windows requested during the previous round
+            // The windows requested during the previous round.  A request is an address in LDS; the 32 x 6 units of a block are
+            // loaded by its 16 lanes twelve apiece, unit after unit, so that the six units of a window (96 contiguous bytes)
+            // sit in neighbouring lanes of one load and coalesce -- a lane loading its own windows would put 64 unrelated
+            // addresses into every load.
+            uint4 pvT[12];
+            uint32_t pvMask = 0;            // which of them hold a requested unit
+            uint64_t* const reqAll = (uint64_t*)(tab + 4096 + 1024 + 32 * 4 * kSpecWinDw + 32 * kSpecRound);
+            static_assert(4096 + 1024 + 32 * 4 * kSpecWinDw + 32 * kSpecRound + 32 * 8 <= kHufJobBytes, "window requests fit in the job's LDS");
             uint8_t* tmpL[2]; uint32_t* winL[2]; uint32_t* soL[2]; uint16_t* ckL[2];
 #pragma unroll
             for (int c = 0; c < 2; c++) {
@@ -797,25 +804,34 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
                         wbL[c] = wbS[c];
 #pragma unroll
                         for (int u = 0; u < 6; u++) *(uint4*)(winL[c] + 4 * u) = v[c][u];
-                    } else if (hasPv[c]) {
-                        wbL[c] = pwb[c];
-#pragma unroll
-                        for (int u = 0; u < 6; u++) *(uint4*)(winL[c] + 4 * u) = pv[c][u];
-                    }
+                    } else if (hasPv[c]) wbL[c] = pwb[c];
                     hasPv[c] = false;
                 }
+                if (!stage) {
+#pragma unroll
+                    for (uint32_t i = 0; i < 12; i++) {
+                        uint32_t const g = 16 * i + sl, X = (g * 171u) >> 10, u = g - 6 * X;      // unit u of chain X (g / 6 for g < 192)
+                        if ((pvMask >> i) & 1) *(uint4*)(winAll + X * kSpecWinDw + 4 * u) = pvT[i];
+                    }
+                }
+                pvMask = 0;
                 lds_sync();
 #pragma unroll
                 for (int c = 0; c < 2; c++) {
                     // The window the next round will start from -- when the one in place would not feed it: what is left now,
                     // less what this round will take (about what the last one took), against the most a round can take.
                     int const left = (int)(8 * (int64_t)((uintptr_t)myStart - wbL[c])) + cur[c];
-                    if (act[c] && left - (int)(lastUse[c] + lastUse[c] / 4 + 16) < (int)(tableLog * kSpecRound + 96)) {
-                        pwb[c] = window_base(cur[c]);
+                    bool const need = act[c] && left - (int)(lastUse[c] + lastUse[c] / 4 + 16) < (int)(tableLog * kSpecRound + 96);
+                    if (need) { pwb[c] = window_base(cur[c]); hasPv[c] = true; }
+                    reqAll[sl + 16 * c] = need ? (uint64_t)pwb[c] : 0ull;
+                }
+                lds_sync();
 #pragma unroll
-                        for (int u = 0; u < 6; u++) pv[c][u] = ld_unit_any(pwb[c] + 16 * u, floorAddr);
-                        hasPv[c] = true;
-                    }
+                for (uint32_t i = 0; i < 12; i++) {
+                    uint32_t const g = 16 * i + sl, X = (g * 171u) >> 10, u = g - 6 * X;
+                    uint64_t const base = reqAll[X];
+                    pvT[i] = ld_unit_any(base ? (uintptr_t)base + 16 * u : floorAddr, floorAddr);       // (every lane loads: a fixed number of loads in flight)
+                    pvMask |= base ? (1u << i) : 0u;
                 }
                 // The previous round's bytes go to the parts' scratch regions: behind the window requests, which must not wait
                 // for these stores to be acknowledged.
