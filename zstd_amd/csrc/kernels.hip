@@ -2317,14 +2317,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
             uint32_t const bstart = rc.y;
             q.lstart = rc.z;
             q.ll = q.have ? rc.w : 0;
-            q.off = q.have ? rep_subst(rc.x, rin0, rin1, rin2) : 1;
+            // (straight-line on purpose, selects and bitwise logic instead of branches: a branch costs this single wave more
+            // than the few instructions it would skip)
+            uint32_t const offR = rep_subst(rc.x, rin0, rin1, rin2);
+            q.off = q.have ? offR : 1;
             // per-sequence checks in the order of ZSTD_execSequenceEnd / ZSTD_execSequence (:896-1008)
-            uint32_t code = 0;
-            if (q.have) {
-                if (nstart > room) code = E_dstSize_tooSmall;
-                else if ((uint64_t)q.lstart + q.ll > litSize) code = E_corruption;
-                else if ((uint64_t)q.off > bo + bstart + q.ll + dictN) code = E_corruption;
-            }
+            bool const e1 = nstart > room;
+            bool const e2 = (uint64_t)q.lstart + q.ll > litSize;
+            bool const e3 = (uint64_t)q.off > bo + bstart + q.ll + dictN;
+            uint32_t const code = !q.have ? 0u : e1 ? (uint32_t)E_dstSize_tooSmall : (e2 | e3) ? (uint32_t)E_corruption : 0u;
             unsigned long long const bad = __ballot(code != 0);
             q.err = bad ? uni((uint32_t)__shfl(code, __builtin_ctzll(bad))) : 0u;
             q.ml = nstart - bstart - q.ll;
@@ -2338,25 +2339,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
             // text) depend on bytes of the batch itself, or repeat a pattern.
             int64_t const ms = (int64_t)(q.start + q.ll) - (int64_t)q.off;          // batch-relative source start
             q.absS = batchAbs + ms;
-            q.plain = q.have && q.off >= q.ml && ms + (int64_t)q.ml <= 0 && (q.absS >= 0 || q.absS + (int64_t)q.ml <= 0);
+            q.plain = q.have & (q.off >= q.ml) & (ms + (int64_t)q.ml <= 0) & ((q.absS >= 0) | (q.absS + (int64_t)q.ml <= 0));
             // Batches of short runs (the usual case) are assembled in LDS; there a plain match is fetched as 16 or 32
             // bytes whatever its length, which must stay inside the frame's output area or the dictionary.
             q.lit0 = lane_value(q.lstart, 0);
             q.sumLL = endZ - q.lit0;          // the literals of a batch are contiguous
             int64_t const fetchEnd = q.absS + (q.ml > 16 ? 32 : 16);
-            bool const fetchable = q.plain && (q.absS >= 0 ? fetchEnd <= (int64_t)cap : fetchEnd <= 0);
-            uint32_t const slowS = (q.have && !fetchable) ? q.ml : 0;
+            bool const fetchable = q.plain & (q.absS >= 0 ? fetchEnd <= (int64_t)cap : fetchEnd <= 0);
+            uint32_t const slowS = (q.have & !fetchable) ? q.ml : 0;
             // of a match handled in LDS, the leading bytes whose source lies before the batch come from memory, one per lane
             int64_t const lead = -ms < (int64_t)(q.ml < q.off ? q.ml : q.off) ? -ms : (int64_t)(q.ml < q.off ? q.ml : q.off);
-            q.gcnt = (slowS && lead > 0) ? (uint32_t)lead : 0u;
+            q.gcnt = ((slowS != 0) & (lead > 0)) ? (uint32_t)lead : 0u;
             q.gEnd = wave_incl_scan(q.gcnt);
-            q.staged = q.total <= kOutStage && q.sumLL <= kLitStage && lane_value(q.gEnd, 63) <= 64 && !__any(q.ll > 32 || (q.plain && q.ml > 32));
+            bool const longRun = __any((q.ll > 32) | (q.plain & (q.ml > 32)));
+            q.staged = (q.total <= kOutStage) & (q.sumLL <= kLitStage) & (lane_value(q.gEnd, 63) <= 64) & !longRun;
             // the batch goes right behind the previous one; when the stage is full the last kOutKeep bytes of history move to
             // the front first (`shift` = how far)
             q.hp = (q.staged && prevStaged) ? (prevEnd + q.total <= kOutHist ? prevEnd : (prevEnd < kOutKeep ? prevEnd : kOutKeep)) : 0u;
             q.shift = (q.staged && prevStaged) ? prevEnd - q.hp : 0u;
-            q.nearS = fetchable && (uint64_t)(-ms) <= q.hp;          // source inside the history: no fetch
-            q.fastS = fetchable && !q.nearS;
+            q.nearS = fetchable & ((uint64_t)(-ms) <= q.hp);          // source inside the history: no fetch
+            q.fastS = fetchable & !q.nearS;
             return q;
         };
         Plan pl = {};
