@@ -1736,9 +1736,11 @@ __global__ __launch_bounds__(kSeqThreads) void k_sequences(BatchParams p)
 #ifdef ZG_STAMPS
     kSetup = __builtin_readcyclecounter() - k0;
 #endif
+    bool chainAct = true;       // the chain wave's own copy of the flag it publishes (no LDS round trip at the top of its rounds)
     for (uint32_t k = 0;; k++) {
         uint32_t const par = k & 1;
-        bool const act = activeFlag[par] != 0;
+        bool act;
+        if (chain) act = chainAct; else act = activeFlag[par] != 0;
         if (chain) {
             // ---- the serial chains, round k
             if (act) {
@@ -1812,6 +1814,7 @@ __global__ __launch_bounds__(kSeqThreads) void k_sequences(BatchParams p)
                 if (role == 0) pub[par][slot] = make_uint2(Q, n);
                 bool const anyLeft = __any(remaining != 0);
                 if (lane == 0) activeFlag[par ^ 1] = anyLeft ? 1u : 0u;
+                chainAct = anyLeft;
             }
         } else if (helper && k >= 1 && !dead) {
             // ---- helpers, round k-1
