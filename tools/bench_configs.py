@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
 """Side measurements on BASELINE.json's other configurations (not the bench.py contract line):
+   C2t / C2b  the benchmark shape (4096 level-3 frames of 128 KiB) on one corpus only: text-like, binary records
+   C2m  the same shape as 512 frames of eight blocks (1 MiB each): tables repeated and windows carried across blocks
    C3  level-19 frames of 128 KiB with checksums
    C5  4 KB records compressed with a trained dictionary, many small frames
 Prints one line per configuration: decompressed GB/s and per-stage milliseconds."""
@@ -68,6 +70,7 @@ def run(name, frames, capacities, plain, dictionary=None, steps=5):
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--c2-frames", type=int, default=4096)
     ap.add_argument("--c3-frames", type=int, default=1024)
     ap.add_argument("--c5-frames", type=int, default=65536)
     args = ap.parse_args()
@@ -75,6 +78,22 @@ def main():
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import gen_fixtures
     z = corpus.SystemZstd()
+    if args.c2_frames:
+        from concurrent.futures import ThreadPoolExecutor
+        import threading
+        tls = {}
+
+        def comp(pl):
+            return tls.setdefault(threading.get_ident(), corpus.SystemZstd()).compress(pl, 3)
+        for name, gen in (("C2t text-like only", corpus.text_like), ("C2b binary records only", corpus.binary_records)):
+            plain = [gen(20_000 + i, 131072) for i in range(args.c2_frames)]
+            with ThreadPoolExecutor(16) as ex:
+                frames = list(ex.map(comp, plain))
+            run(name, frames, [131072] * len(frames), plain)
+        plain = [corpus.mixed(30_000 + i, 1 << 20) for i in range(args.c2_frames // 8)]
+        with ThreadPoolExecutor(16) as ex:
+            frames = list(ex.map(comp, plain))
+        run("C2m 1 MiB frames of eight blocks", frames, [1 << 20] * len(frames), plain)
     plain = [corpus.mixed(10_000 + i, 131072) for i in range(args.c3_frames)]
     frames = [z.compress(p, 19, True) for p in plain]
     run("C3 level 19 + checksum", frames, [131072] * len(frames), plain)
