@@ -209,6 +209,33 @@ void zstdgpu_batch_destroy(zstdgpu_batch* batch);
  * Asynchronous; allocates nothing.  Returns 0 or an error code (GENERIC on a launch failure). */
 size_t zstdgpu_batch_decode(zstdgpu_batch* batch, const void* devSrc, void* devDst, void* stream);
 
+/* ---- one entry point that allocates nothing ----
+ * No counterpart in the reference.  It is for callers that cannot allocate device memory: code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc.  It does what zstdgpu_batch_create_on_device +
+ * zstdgpu_batch_decode do (device-side header walk, then the whole stage chain) with every intermediate buffer in one
+ * fixed device array of ZSTDGPU_NOALLOC_SCRATCH_MIB MiB that each GPU holds from zstdgpu_create until the process
+ * ends; it calls no hipMalloc / hipFree, copies nothing to or from the host and does not wait.
+ *   devSrc, devFrames   DEVICE memory: the compressed frames and one zstdgpu_frame_in per frame (one zstd frame each)
+ *   devDst, devStatus   DEVICE memory: the regenerated bytes and one zstdgpu_frame_status per frame, valid once the
+ *                       stream has reached the end of the call's work
+ * Limits: nFrames <= ZSTDGPU_NOALLOC_MAX_FRAMES and srcBytes <= ZSTDGPU_NOALLOC_MAX_SRC_BYTES, else the call returns
+ * parameter_outOfBound and launches nothing.  What only the frames' contents tell is checked on the device: more than
+ * ZSTDGPU_NOALLOC_MAX_BLOCKS blocks, ZSTDGPU_NOALLOC_MAX_LITERAL_BYTES Huffman-coded literal bytes or
+ * ZSTDGPU_NOALLOC_MAX_SEQUENCES sequence records (sequences + 65 per block) in the batch: every frame of the call
+ * gets errorCode memory_allocation and nothing is decoded.
+ * All calls on one GPU share that GPU's array: calls that overlap in time on one GPU race, whatever their streams
+ * and contexts; calls in one stream are ordered.  The context's format / checksum parameters apply. */
+#define ZSTDGPU_NOALLOC_MAX_FRAMES 256u
+#define ZSTDGPU_NOALLOC_MAX_SRC_BYTES (4u << 20)
+#define ZSTDGPU_NOALLOC_MAX_BLOCKS 1024u
+#define ZSTDGPU_NOALLOC_MAX_LITERAL_BYTES (4u << 20)
+#define ZSTDGPU_NOALLOC_MAX_SEQUENCES (1u << 18)
+#define ZSTDGPU_NOALLOC_SCRATCH_MIB 22u
+size_t zstdgpu_decode_frames_noalloc(zstdgpu_ctx* ctx, const void* devSrc, size_t srcBytes,
+                                     const zstdgpu_frame_in* devFrames, uint32_t nFrames,
+                                     void* devDst, zstdgpu_frame_status* devStatus,
+                                     const zstdgpu_ddict* ddict, void* stream);
+
 /* Wait for the last launch and copy the per-frame verdicts out (`status` has nFrames entries). */
 size_t zstdgpu_batch_status(zstdgpu_batch* batch, zstdgpu_frame_status* status);
 

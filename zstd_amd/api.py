@@ -70,6 +70,7 @@ EXPORTS = (
     "zstdgpu_dParam_getBounds", "zstdgpu_DCtx_setParameter", "zstdgpu_DCtx_getParameter", "zstdgpu_DCtx_refDDict", "zstdgpu_DCtx_reset",
     "zstdgpu_batch_decode", "zstdgpu_batch_status", "zstdgpu_batch_nFrames", "zstdgpu_batch_nBlocks", "zstdgpu_batch_srcBytes",
     "zstdgpu_batch_scratchBytes", "zstdgpu_batch_set_profiling", "zstdgpu_batch_stage_ms", "zstdgpu_stage_kernel_name",
+    "zstdgpu_decode_frames_noalloc",
     "zstdgpu_xxh64Batch", "zstdgpu_batch_blockInfo", "zstdgpu_batch_copyLiterals", "zstdgpu_batch_copySequences",
 )
 
@@ -148,6 +149,7 @@ def lib():
     proto("zstdgpu_batch_destroy", None, vp)
     proto("zstdgpu_batch_decode", sz, vp, vp, vp, vp)
     proto("zstdgpu_batch_status", sz, vp, vp)
+    proto("zstdgpu_decode_frames_noalloc", sz, vp, vp, sz, vp, u32, vp, vp, vp, vp)
     proto("zstdgpu_batch_nFrames", u32, vp)
     proto("zstdgpu_batch_nBlocks", u32, vp)
     proto("zstdgpu_batch_srcBytes", u64, vp)
@@ -405,6 +407,16 @@ class Batch:
             self.close()
         except Exception:
             pass
+
+
+NOALLOC_MAX_FRAMES, NOALLOC_MAX_SRC_BYTES = 256, 4 << 20
+
+
+def decode_frames_noalloc(dctx: DCtx, dev_src_ptr: int, src_bytes: int, dev_frames_ptr: int, n_frames: int,
+                          dev_dst_ptr: int, dev_status_ptr: int, ddict: DDict = None, stream: int = 0):
+    """zstdgpu_decode_frames_noalloc: everything in device memory, nothing allocated, nothing awaited."""
+    _check(lib().zstdgpu_decode_frames_noalloc(dctx.h, dev_src_ptr, src_bytes, dev_frames_ptr, n_frames, dev_dst_ptr, dev_status_ptr,
+                                               ddict.h if ddict else None, stream or None))
 
 
 def xxh64_batch(dctx: DCtx, dev_base_ptr: int, offsets, lengths) -> np.ndarray:

@@ -190,7 +190,8 @@ DEVI uint64_t wg_excl_scan(uint64_t v, uint64_t* waveTot, uint64_t& total)
 
 // ---- exclusive prefix sum of the slots into frames[].firstBlock; total -> totals[0].  One workgroup, tiles of
 // kScanThreads frames.
-__global__ __launch_bounds__(kScanThreads) void k_first_blocks(const uint32_t* slots, const FrameIn* in, uint32_t nFrames, DevFrame* frames, uint64_t* totals)
+__global__ __launch_bounds__(kScanThreads) void k_first_blocks(const uint32_t* slots, const FrameIn* in, uint32_t nFrames, DevFrame* frames, uint64_t* totals,
+                                                               uint32_t maxBlocks)
 {
     __shared__ uint64_t waveTot[kScanThreads / 64];
     uint32_t const t = threadIdx.x;
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(kScanThreads) void k_first_blocks(const uint32_t* s
         carry += tileTotal;
     }
     if (bytes) atomicAdd((unsigned long long*)&totals[6], (unsigned long long)bytes);      // source bytes of the frames that will be decoded
-    if (t == 0) totals[0] = carry;
+    if (t == 0) { totals[0] = carry; if (maxBlocks && carry > maxBlocks) totals[7] = 1; }
 }
 
 // ---- launch 2: the block descriptors of every frame.  The scratch offsets hold the block's needs for now
@@ -215,10 +216,11 @@ __global__ __launch_bounds__(kScanThreads) void k_first_blocks(const uint32_t* s
 // with an error stay zero.
 __global__ __launch_bounds__(64) void k_fill_blocks(const uint8_t* src, uint64_t srcBytes, const FrameIn* in, uint32_t nFrames,
                                                     uint32_t batchDictID, uint32_t opts, uint32_t dictEntropy, const DevFrame* frames,
-                                                    DevBlock* blocks, uint8_t* flags)
+                                                    DevBlock* blocks, uint8_t* flags, const uint64_t* totals, uint32_t maxBlocks)
 {
     uint32_t const fi = blockIdx.x * 64 + threadIdx.x;
     if (fi >= nFrames) return;
+    if (maxBlocks && totals[7]) return;     // more blocks than the fixed block array holds: nothing is filled
     DevFrame const fr = frames[fi];
     if (fr.hostError) return;
     uint32_t const first = fr.firstBlock;
@@ -270,10 +272,14 @@ __global__ __launch_bounds__(64) void k_fill_blocks(const uint8_t* src, uint64_t
 // tile), the sequence records and the two job counts another.
 // totals: [1] literal buffer bytes, [2] split-decode scratch bytes, [3] sequence records, [4] literal jobs, [5] sequence jobs.
 __global__ __launch_bounds__(kScanThreads) void k_block_offsets(DevBlock* blocks, const uint8_t* flags, uint32_t nBlocks,
-                                                                uint32_t* litJobs, uint32_t* seqJobs, uint64_t* totals)
+                                                                uint32_t* litJobs, uint32_t* seqJobs, uint64_t* totals, ScratchCaps caps)
 {
     __shared__ uint64_t waveTot[kScanThreads / 64];
     uint32_t const t = threadIdx.x;
+    if (caps.maxBlocks) {       // fixed scratch: the block count is on the device only
+        if (totals[7]) return;
+        nBlocks = (uint32_t)totals[0];
+    }
     uint64_t cLit = 0, cTmp = 0, cSeq = 0, cLitJobs = 0, cSeqJobs = 0;
     for (uint32_t base = 0; base < nBlocks; base += kScanThreads) {
         uint32_t const b = base + t;
@@ -296,25 +302,28 @@ __global__ __launch_bounds__(kScanThreads) void k_block_offsets(DevBlock* blocks
         cLit += (uint32_t)totA; cTmp += totA >> 32;
         cSeq += (uint32_t)totB; cLitJobs += (totB >> 32) & 0xFFFF; cSeqJobs += totB >> 48;
     }
-    if (t == 0) { totals[1] = cLit; totals[2] = cTmp; totals[3] = cSeq; totals[4] = cLitJobs; totals[5] = cSeqJobs; }
+    if (t == 0) {
+        totals[1] = cLit; totals[2] = cTmp; totals[3] = cSeq; totals[4] = cLitJobs; totals[5] = cSeqJobs;
+        if (caps.maxBlocks && (cLit + 64 > caps.litBytes || cTmp + 64 > caps.tmpBytes || cSeq + 1 > caps.seqRecords)) totals[7] = 1;
+    }
 }
 
 }  // namespace
 
 void launch_scan_frames(const uint8_t* src, uint64_t srcBytes, const FrameIn* in, uint32_t nFrames, uint32_t batchDictID, uint32_t opts,
-                        DevFrame* frames, uint32_t* slots, uint64_t* totals, void* stream)
+                        DevFrame* frames, uint32_t* slots, uint64_t* totals, void* stream, ScratchCaps caps)
 {
     if (nFrames) hipLaunchKernelGGL(k_scan_frames, dim3((nFrames + 63) / 64), dim3(64), 0, (hipStream_t)stream, src, srcBytes, in, nFrames, batchDictID, opts, frames, slots);
     hipMemsetAsync(totals, 0, 8 * sizeof(uint64_t), (hipStream_t)stream);
-    hipLaunchKernelGGL(k_first_blocks, dim3(1), dim3(kScanThreads), 0, (hipStream_t)stream, slots, in, nFrames, frames, totals);
+    hipLaunchKernelGGL(k_first_blocks, dim3(1), dim3(kScanThreads), 0, (hipStream_t)stream, slots, in, nFrames, frames, totals, caps.maxBlocks);
 }
 
 void launch_fill_blocks(const uint8_t* src, uint64_t srcBytes, const FrameIn* in, uint32_t nFrames, uint32_t batchDictID, uint32_t opts,
                         uint32_t dictEntropy, const DevFrame* frames, DevBlock* blocks, uint8_t* flags, uint32_t nBlocks,
-                        uint32_t* litJobs, uint32_t* seqJobs, uint64_t* totals, void* stream)
+                        uint32_t* litJobs, uint32_t* seqJobs, uint64_t* totals, void* stream, ScratchCaps caps)
 {
-    if (nFrames) hipLaunchKernelGGL(k_fill_blocks, dim3((nFrames + 63) / 64), dim3(64), 0, (hipStream_t)stream, src, srcBytes, in, nFrames, batchDictID, opts, dictEntropy, frames, blocks, flags);
-    hipLaunchKernelGGL(k_block_offsets, dim3(1), dim3(kScanThreads), 0, (hipStream_t)stream, blocks, flags, nBlocks, litJobs, seqJobs, totals);
+    if (nFrames) hipLaunchKernelGGL(k_fill_blocks, dim3((nFrames + 63) / 64), dim3(64), 0, (hipStream_t)stream, src, srcBytes, in, nFrames, batchDictID, opts, dictEntropy, frames, blocks, flags, totals, caps.maxBlocks);
+    hipLaunchKernelGGL(k_block_offsets, dim3(1), dim3(kScanThreads), 0, (hipStream_t)stream, blocks, flags, nBlocks, litJobs, seqJobs, totals, caps);
 }
 
 }  // namespace zg

@@ -25,6 +25,12 @@ namespace {
 // ---------------------------------------------------------------- small helpers
 DEVI uint32_t hb32(uint32_t v) { return 31u - (uint32_t)__builtin_clz(v); }
 
+// Job counts of a batch: launch parameters, or -- for a batch whose descriptors never left the device -- the device
+// totals (none when the batch does not fit its scratch).
+DEVI bool batch_overflow(const BatchParams& p) { return p.devTotals && p.devTotals[7] != 0; }
+DEVI uint32_t n_lit_jobs(const BatchParams& p) { return p.devTotals ? (p.devTotals[7] ? 0u : (uint32_t)p.devTotals[4]) : p.nLitJobs; }
+DEVI uint32_t n_seq_jobs(const BatchParams& p) { return p.devTotals ? (p.devTotals[7] ? 0u : (uint32_t)p.devTotals[5]) : p.nSeqJobs; }
+
 // orders LDS and global accesses of the lanes of this (single-wave) workgroup
 DEVI void wave_sync()
 {
@@ -556,7 +562,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
     uint32_t const lane = threadIdx.x;
     uint32_t const sub = lane / kHufLanes, sl = lane % kHufLanes;
     uint32_t const job = blockIdx.x * kHufJobs + sub;
-    if (job >= p.nLitJobs) return;
+    if (job >= n_lit_jobs(p)) return;
     uint32_t const b = p.litJobs[job];
     DevBlock const blk = p.blocks[b];
     uint8_t* const tab = lds + sub * kHufJobBytes;
@@ -1118,6 +1124,7 @@ __global__ __launch_bounds__(kPackThreads) __attribute__((amdgpu_waves_per_eu(4,
 {
     __shared__ uint4 parts[32];
     uint32_t const job = blockIdx.x, tid = threadIdx.x;
+    if (job >= n_lit_jobs(p)) return;
     const uint4* const tab = p.packTab + (size_t)job * kPackTabEntries;
     if (tab[32].x == 0) return;
     if (tid < 32) parts[tid] = tab[tid];
@@ -1566,7 +1573,7 @@ __global__ __launch_bounds__(kSeqThreads) void k_sequences(BatchParams p)
     uint32_t const slot = helper ? (wave - 1) * 4 + (lane >> 4) : (lane >> 2);       // block slot inside the workgroup
     uint32_t const role = lane & 3;            // chain wave: which of a block's four chain lanes this is (LL, ML, OF, cursor)
     uint32_t const job = blockIdx.x * kSeqJobs + slot;
-    bool const hasJob = job < p.nSeqJobs;
+    bool const hasJob = job < n_seq_jobs(p);
     uint32_t* const tLL = lds + slot * kSeqJobWords;
     uint32_t* const tML = tLL + 512;
     uint32_t* const tOF = tML + 512;
@@ -1974,6 +1981,7 @@ __global__ void k_layout(BatchParams p)
     fs->xxh64Low32 = 0; fs->regenSize = 0;
     fs->errorCode = f.hostError;
     if (f.hostError) return;
+    if (batch_overflow(p)) { fs->errorCode = E_memory_allocation; return; }     // the batch exceeds its fixed scratch
     if (f.useDict && p.dict->status) { fs->errorCode = p.dict->status; return; }
     uint32_t rep[3] = {1, 4, 8};   // repStartValue (zstd_internal.pas:13)
     if (f.useDict && p.dict->hasEntropy) { rep[0] = p.dict->rep[0]; rep[1] = p.dict->rep[1]; rep[2] = p.dict->rep[2]; }

@@ -12,6 +12,7 @@
 
 #include "../../include/zstdgpu.h"
 #include "zstdgpu_internal.h"
+#include "zstdgpu_objects.h"
 
 using namespace zg;
 
@@ -156,33 +157,7 @@ size_t walk_frame(const uint8_t* base, const zstdgpu_frame_in& in, uint32_t fram
 
 }  // namespace
 
-// ===================================================================== objects
-struct zstdgpu_ctx {
-    int device = 0;
-    // grow-only device staging for the host-buffer drop-ins
-    uint8_t *dSrc = nullptr, *dDst = nullptr;
-    size_t dSrcCap = 0, dDstCap = 0;
-    // device buffers of destroyed batches, kept for the next batch (hipMalloc of the hundreds of MB of
-    // literal/sequence scratch costs tens of milliseconds; a steady stream of batches should not pay it again)
-    struct Spare { void* p; size_t bytes; };
-    std::vector<Spare> spare;
-    // decoder parameters (ZSTD_DCtx_resetParameters, zstd_decompressf.pas:131-139) and the referenced dictionary
-    uint32_t format = 0;                          // ZSTD_f_zstd1 / ZSTD_f_zstd1_magicless
-    uint64_t maxWindowSize = (1ull << 27) + 1;    // ZSTD_MAXWINDOWSIZE_DEFAULT (:51)
-    uint32_t stableOut = 0, ignoreChecksum = 0;
-    const zstdgpu_ddict* refDDict = nullptr;
-    std::vector<zstdgpu_dstream*> streams;        // streams opened on this context
-    uint32_t opts() const { return (format ? kOptMagicless : 0u) | (ignoreChecksum ? kOptIgnoreChecksum : 0u); }
-    void reset_parameters() { format = 0; maxWindowSize = (1ull << 27) + 1; stableOut = 0; ignoreChecksum = 0; }
-};
-
-struct zstdgpu_ddict {
-    zstdgpu_ctx* ctx = nullptr;
-    uint8_t* dBytes = nullptr;     // whole dictionary on the device
-    DevDict* dDict = nullptr;
-    uint32_t size = 0, dictID = 0, hasEntropy = 0, entropySize = 0, status = 0;
-};
-
+// ===================================================================== objects (context and dictionary: zstdgpu_objects.h)
 struct zstdgpu_batch {
     zstdgpu_ctx* ctx = nullptr;
     const zstdgpu_ddict* ddict = nullptr;
@@ -352,7 +327,7 @@ extern "C" zstdgpu_ctx* zstdgpu_create(int device)
     if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return nullptr;
     if (hipSetDevice(device) != hipSuccess) return nullptr;
     zstdgpu_ctx* c = new (std::nothrow) zstdgpu_ctx;
-    if (c) c->device = device;
+    if (c) { c->device = device; c->scratch = noalloc_scratch(device); }
     return c;
 }
 extern "C" void zstdgpu_destroy(zstdgpu_ctx* ctx)

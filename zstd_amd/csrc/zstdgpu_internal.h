@@ -111,6 +111,10 @@ struct BatchParams {
     const uint8_t* dictContent;  // device pointer to dictionary content
     uint32_t dictContentSize;
     uint32_t nLitJobs, nSeqJobs, nFrames, nBlocks;
+    // When set, the block and job counts are read from these device totals (layout of the descriptor builder's
+    // `totals`) instead of the fields above, which then only bound the grids: the descriptors were built on the
+    // device and nothing came back to the host.  totals[7] != 0: the batch does not fit its scratch, nothing is decoded.
+    const uint64_t* devTotals;
 #ifdef ZG_STAMPS
     uint64_t* dbg;               // diagnostic build only: 4 cycle counters per block
 #endif
@@ -119,14 +123,18 @@ struct BatchParams {
 // One source frame of a batch (same layout as zstdgpu_frame_in).
 struct FrameIn { uint64_t srcOff, srcSize, dstOff, dstCapacity; };
 
+// Capacities of a fixed scratch area (all zero: no limit, the host sizes the buffers from the totals).  With limits the
+// builder compares its totals with them on the device and raises totals[7] instead of reporting back to the host.
+struct ScratchCaps { uint32_t maxBlocks; uint64_t litBytes, tmpBytes, seqRecords; };
+
 // descriptor builder on the device (descriptors.hip).  totals: [0] block slots, [1] literal buffer bytes,
 // [2] split-decode scratch bytes, [3] sequence records, [4] literal jobs, [5] sequence jobs, [6] source bytes of the
-// frames without a header error (8 entries)
+// frames without a header error, [7] the batch exceeds the scratch capacities (8 entries)
 void launch_scan_frames(const uint8_t* src, uint64_t srcBytes, const FrameIn* in, uint32_t nFrames, uint32_t batchDictID, uint32_t opts,
-                        DevFrame* frames, uint32_t* slots, uint64_t* totals, void* stream);
+                        DevFrame* frames, uint32_t* slots, uint64_t* totals, void* stream, ScratchCaps caps = ScratchCaps{0, 0, 0, 0});
 void launch_fill_blocks(const uint8_t* src, uint64_t srcBytes, const FrameIn* in, uint32_t nFrames, uint32_t batchDictID, uint32_t opts,
                         uint32_t dictEntropy, const DevFrame* frames, DevBlock* blocks, uint8_t* flags, uint32_t nBlocks,
-                        uint32_t* litJobs, uint32_t* seqJobs, uint64_t* totals, void* stream);
+                        uint32_t* litJobs, uint32_t* seqJobs, uint64_t* totals, void* stream, ScratchCaps caps = ScratchCaps{0, 0, 0, 0});
 
 // kernel launchers (kernels.hip)
 void launch_literals(const BatchParams& p, void* stream);

@@ -1,0 +1,44 @@
+// The context and dictionary objects behind the opaque handles of include/zstdgpu.h, shared by the source files
+// of the host library.
+#pragma once
+#include <stdint.h>
+
+#include <vector>
+
+#include "../../include/zstdgpu.h"
+#include "zstdgpu_internal.h"
+
+struct zstdgpu_dstream;
+
+struct zstdgpu_ctx {
+    int device = 0;
+    // grow-only device staging for the host-buffer drop-ins
+    uint8_t *dSrc = nullptr, *dDst = nullptr;
+    size_t dSrcCap = 0, dDstCap = 0;
+    // device buffers of destroyed batches, kept for the next batch (hipMalloc of the hundreds of MB of
+    // literal/sequence scratch costs tens of milliseconds; a steady stream of batches should not pay it again)
+    struct Spare { void* p; size_t bytes; };
+    std::vector<Spare> spare;
+    // decoder parameters (ZSTD_DCtx_resetParameters, zstd_decompressf.pas:131-139) and the referenced dictionary
+    uint32_t format = 0;                          // ZSTD_f_zstd1 / ZSTD_f_zstd1_magicless
+    uint64_t maxWindowSize = (1ull << 27) + 1;    // ZSTD_MAXWINDOWSIZE_DEFAULT (:51)
+    uint32_t stableOut = 0, ignoreChecksum = 0;
+    const zstdgpu_ddict* refDDict = nullptr;
+    std::vector<zstdgpu_dstream*> streams;        // streams opened on this context
+    uint8_t* scratch = nullptr;                   // this device's fixed scratch array (zstdgpu_decode_frames_noalloc)
+    uint32_t opts() const { return (format ? zg::kOptMagicless : 0u) | (ignoreChecksum ? zg::kOptIgnoreChecksum : 0u); }
+    void reset_parameters() { format = 0; maxWindowSize = (1ull << 27) + 1; stableOut = 0; ignoreChecksum = 0; }
+};
+
+struct zstdgpu_ddict {
+    zstdgpu_ctx* ctx = nullptr;
+    uint8_t* dBytes = nullptr;     // whole dictionary on the device
+    zg::DevDict* dDict = nullptr;
+    uint32_t size = 0, dictID = 0, hasEntropy = 0, entropySize = 0, status = 0;
+};
+
+
+namespace zg {
+// This device's copy of the fixed scratch array of the no-allocation entry point (noalloc.hip); nullptr on failure.
+uint8_t* noalloc_scratch(int device);
+}  // namespace zg
