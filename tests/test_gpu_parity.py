@@ -219,6 +219,77 @@ def test_truncated_capacity_and_isolated_errors(dctx):
     b.close()
 
 
+# ------------------------------------------------------------------ object lifetimes
+def test_destroy_without_status_then_next_batch(dctx):
+    """A batch destroyed right after its (asynchronous) launch hands its big buffers to the next batch: the second
+    batch, launched on another stream, must still decode correctly, and so must the first one's output."""
+    import torch
+    big = [e for e in FRAMES if e["name"] in ("text1m_l1", "bin512k_l3_c1", "text300k_l19_c1")]
+    frames = [read_frame(e) for e in big] * 4
+    caps = [e["capacity"] for e in big] * 4
+    src, fin, dst_bytes = api.pack_frames(frames, caps)
+    d_src = dev(src)
+    want = [oracle.decompress(f, c)[0] for f, c in zip(frames[:3], caps[:3])] * 4
+    outs = []
+    for k in range(3):
+        s = torch.cuda.Stream()
+        d_dst = torch.zeros(dst_bytes, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        b = api.Batch(dctx, src, fin)
+        b.decode(d_src.data_ptr(), d_dst.data_ptr(), s.cuda_stream)
+        b.close()                      # no status call, no wait by the caller
+        outs.append(d_dst)
+    torch.cuda.synchronize()
+    for d_dst in outs:
+        out = d_dst.cpu().numpy()
+        for i, w in enumerate(want):
+            o = int(fin[i]["dstOff"])
+            assert out[o:o + len(w)].tobytes() == w
+
+
+def test_context_closed_before_its_children():
+    """zstdgpu_destroy with a dictionary and a stream still alive: freeing them afterwards is harmless, and the orphaned
+    stream refuses work."""
+    d = api.DCtx(0)
+    dd = api.DDict(d, read_dict("dict16k"))
+    zs = api.DStream(d)
+    d.close()
+    with pytest.raises(api.ZstdError) as ex:
+        zs.decompress_stream(b"\x28\xb5\x2f\xfd", 16)
+    assert ex.value.code == 60
+    zs.close()
+    dd.close()
+
+
+def test_init_stream_cannot_swap_the_dictionary_under_a_busy_stream(dctx):
+    e = next(x for x in FRAMES if x["name"] == "text4096_l3_c1")
+    fr = read_frame(e)
+    dd = api.DDict(dctx, read_dict("dict16k"))
+    a, b = api.DStream(dctx), api.DStream(dctx)
+    r, used, out = a.decompress_stream(fr[:20], 1 << 16)       # stream a is now inside a frame
+    assert r > 0 and used == 20
+    assert api.lib().zstdgpu_isError(api.lib().zstdgpu_initDStream_usingDDict(b.h, dd.h))
+    assert api.lib().zstdgpu_getErrorCode(api.lib().zstdgpu_initDStream_usingDDict(b.h, dd.h)) == 60
+    assert not api.lib().zstdgpu_isError(api.lib().zstdgpu_initDStream(b.h))      # same (no) dictionary: allowed
+    r, used, out2 = a.decompress_stream(fr[20:], 1 << 16)
+    assert r == 0 and out + out2 == regenerate(e["source"])
+    a.close(); b.close(); dd.close()
+
+
+def test_stream_header_cannot_make_the_stream_allocate_its_content_size(dctx):
+    """A 20-byte frame that declares 1 GiB of content in a small window, fed in two pieces (so the one-pass shortcut
+    is off): the stream sizes its output by the blocks that arrived, and reports the damaged frame."""
+    import struct
+    fr = struct.pack("<I", 0xFD2FB528) + bytes([0x80, 0x00]) + struct.pack("<I", 1 << 30) + bytes([0x01, 0x00, 0x00])
+    zs = api.DStream(dctx)
+    r, used, out = zs.decompress_stream(fr[:8], 1 << 16)
+    assert r > 0
+    with pytest.raises(api.ZstdError) as ex:
+        zs.decompress_stream(fr[8:], 1 << 16)
+    assert ex.value.code == 20
+    zs.close()
+
+
 # ------------------------------------------------------------------ descriptors built on the device
 def _both_walks(dctx, frames, caps, ddict=None, extra_in=None):
     """The same input through the host walk and the device walk: descriptor digests, verdicts and bytes must agree."""

@@ -175,6 +175,7 @@ struct zstdgpu_batch {
     hipEvent_t ev[ZSTDGPU_NUM_STAGES + 1] = {};
     bool evReady = false, evRecorded = false;
     hipStream_t lastStream = nullptr;
+    bool launched = false;
     // the literal pack kernel runs beside the sequence kernel on a stream of its own, forked and joined with events
     hipStream_t side = nullptr;
     hipEvent_t evFork = nullptr, evJoin = nullptr;
@@ -281,6 +282,10 @@ void parse_sections(const uint8_t* payload, DevBlock& d)
 
 void free_batch_device(zstdgpu_batch* b)
 {
+    // zstdgpu_batch_decode is asynchronous and nothing obliges the caller to wait before destroying the batch: the
+    // big buffers go back to the context's spare list (no implicit synchronisation as with hipFree), where the next
+    // batch may pick them up and launch on another stream -- so the last launch must be over first.
+    if (b->launched) { hipStreamSynchronize(b->lastStream); if (b->side) hipStreamSynchronize(b->side); }
     hipFree(b->dBlocks); hipFree(b->dState); hipFree(b->dFrames); hipFree(b->dStatus);
     bfree(b->ctx, b->dLitBuf, b->litBufBytes); bfree(b->ctx, b->dLitTmp, b->litTmpBytes); bfree(b->ctx, b->dSeqBuf, b->seqBufBytes);
     hipFree(b->dLitJobs); hipFree(b->dSeqJobs); hipFree(b->dPackTab);
@@ -321,6 +326,8 @@ extern "C" const char* zstdgpu_getErrorName(size_t code)
 }
 
 // ===================================================================== context
+static void stream_detach(zstdgpu_dstream* z);      // a stream whose context is gone: every later call fails
+
 extern "C" zstdgpu_ctx* zstdgpu_create(int device)
 {
     int n = 0;
@@ -334,6 +341,9 @@ extern "C" void zstdgpu_destroy(zstdgpu_ctx* ctx)
 {
     if (!ctx) return;
     set_device(ctx);
+    // dictionaries and streams that outlive the context keep working as far as they can: they forget it
+    for (auto* z : ctx->streams) stream_detach(z);
+    for (auto* d : ctx->ddicts) d->ctx = nullptr;
     hipFree(ctx->dSrc); hipFree(ctx->dDst);
     for (auto& sp : ctx->spare) hipFree(sp.p);
     delete ctx;
@@ -500,7 +510,8 @@ extern "C" zstdgpu_ddict* zstdgpu_createDDict(zstdgpu_ctx* ctx, const void* dict
     if (!ctx || !set_device(ctx) || dictSize > 0x7FFFFFFFu) return nullptr;
     zstdgpu_ddict* d = new (std::nothrow) zstdgpu_ddict;
     if (!d) return nullptr;
-    d->ctx = ctx; d->size = (uint32_t)dictSize;
+    d->ctx = ctx; d->size = (uint32_t)dictSize; d->device = ctx->device;
+    try { ctx->ddicts.push_back(d); } catch (...) { delete d; return nullptr; }
     uint64_t acct = 0;
     if (!dalloc(d->dBytes, dictSize + 16, acct) || !dalloc(d->dDict, 1, acct)) { zstdgpu_freeDDict(d); return nullptr; }
     if (dictSize && hipMemcpy(d->dBytes, dict, dictSize, hipMemcpyHostToDevice) != hipSuccess) { zstdgpu_freeDDict(d); return nullptr; }
@@ -525,8 +536,12 @@ extern "C" zstdgpu_ddict* zstdgpu_createDDict(zstdgpu_ctx* ctx, const void* dict
 extern "C" void zstdgpu_freeDDict(zstdgpu_ddict* d)
 {
     if (!d) return;
-    if (d->ctx && d->ctx->refDDict == d) d->ctx->refDDict = nullptr;   // a freed dictionary is no longer referenced
-    set_device(d->ctx);
+    if (d->ctx) {
+        if (d->ctx->refDDict == d) d->ctx->refDDict = nullptr;   // a freed dictionary is no longer referenced
+        auto& v = d->ctx->ddicts;
+        v.erase(std::remove(v.begin(), v.end(), d), v.end());
+    }
+    hipSetDevice(d->device);
     hipFree(d->dBytes); hipFree(d->dDict);
     delete d;
 }
@@ -535,7 +550,7 @@ extern "C" void zstdgpu_freeDDict(zstdgpu_ddict* d)
 namespace {
 size_t build_descriptors(const void* hostSrc, size_t srcBytes, const zstdgpu_frame_in* in, uint32_t nFrames,
                          zstdgpu_frame_desc* frames, zstdgpu_block_desc* blocks, size_t blockCapacity, uint32_t opts)
-{
+try {
     // dictID checks need the batch dictionary: done again in zstdgpu_batch_create; here any dictID is accepted
     std::vector<zstdgpu_block_desc> tmp;
     size_t nBlocks = 0;
@@ -561,6 +576,7 @@ size_t build_descriptors(const void* hostSrc, size_t srcBytes, const zstdgpu_fra
     }
     return nBlocks;
 }
+catch (...) { return mkerr(E_memory_allocation); }      // the C ABI never throws (std::bad_alloc from the host containers)
 }  // namespace
 extern "C" size_t zstdgpu_buildDescriptors(const void* hostSrc, size_t srcBytes, const zstdgpu_frame_in* in, uint32_t nFrames,
                                            zstdgpu_frame_desc* frames, zstdgpu_block_desc* blocks, size_t blockCapacity)
@@ -580,9 +596,10 @@ extern "C" zstdgpu_batch* zstdgpu_batch_create(zstdgpu_ctx* ctx, const void* hos
     const uint8_t* const src = (const uint8_t*)hostSrc;
     bool const dictEntropy = ddict && ddict->hasEntropy;
     uint32_t const batchDictID = ddict ? ddict->dictID : 0;
+    uint64_t litOff = 0, seqOff = 0, tmpOff = 0;
+    try {
     B->hBlocks.resize(nBlocks);
     B->hFrames.resize(nFrames);
-    uint64_t litOff = 0, seqOff = 0, tmpOff = 0;
     for (uint32_t fi = 0; fi < nFrames; fi++) {
         const zstdgpu_frame_desc& fd = frames[fi];
         DevFrame& f = B->hFrames[fi];
@@ -633,6 +650,7 @@ extern "C" zstdgpu_batch* zstdgpu_batch_create(zstdgpu_ctx* ctx, const void* hos
             }
         }
     }
+    } catch (...) { delete B; return nullptr; }      // the C ABI never throws
     B->litBytes = litOff + 64; B->nSeqTotal = seqOff;
     B->nFrames = nFrames; B->nBlocks = nBlocks; B->nLitJobs = (uint32_t)B->hLitJobs.size(); B->nSeqJobs = (uint32_t)B->hSeqJobs.size();
     bool ok = dalloc(B->dBlocks, nBlocks, B->scratchBytes) && dalloc(B->dState, nBlocks, B->scratchBytes) &&
@@ -650,7 +668,7 @@ extern "C" zstdgpu_batch* zstdgpu_batch_create(zstdgpu_ctx* ctx, const void* hos
 
 extern "C" zstdgpu_batch* zstdgpu_batch_create_from_frames(zstdgpu_ctx* ctx, const void* hostSrc, size_t srcBytes,
                                                            const zstdgpu_frame_in* in, uint32_t nFrames, const zstdgpu_ddict* ddict)
-{
+try {
     if (!ctx) return nullptr;
     uint32_t const opts = ctx->opts();      // the context's frame format and checksum policy apply to the batch
     std::vector<zstdgpu_frame_desc> frames(nFrames);
@@ -661,6 +679,7 @@ extern "C" zstdgpu_batch* zstdgpu_batch_create_from_frames(zstdgpu_ctx* ctx, con
     if (iserr(n2)) return nullptr;
     return zstdgpu_batch_create(ctx, hostSrc, srcBytes, frames.data(), nFrames, blocks.data(), (uint32_t)n2, ddict);
 }
+catch (...) { return nullptr; }      // the C ABI never throws (std::bad_alloc from the host containers)
 
 // The same batch, built without a host copy of the source: the frame / block / section headers are walked by
 // device kernels over the source in device memory (descriptors.hip); the host only sizes the buffers from the
@@ -714,7 +733,7 @@ extern "C" zstdgpu_batch* zstdgpu_batch_create_on_device(zstdgpu_ctx* ctx, const
 
 // Host copies of the descriptor arrays of a batch that was built on the device.
 static bool mirror(zstdgpu_batch* B)
-{
+try {
     if (B->mirrored) return true;
     if (!set_device(B->ctx)) return false;
     B->hBlocks.resize(B->nBlocks); B->hFrames.resize(B->nFrames); B->hLitJobs.resize(B->nLitJobs); B->hSeqJobs.resize(B->nSeqJobs);
@@ -724,6 +743,7 @@ static bool mirror(zstdgpu_batch* B)
     B->mirrored = ok;
     return ok;
 }
+catch (...) { return false; }      // the C ABI never throws (std::bad_alloc from the host containers)
 
 // FNV-1a over the descriptor arrays of a batch (blocks, frames, job lists): two batches built from the same input by
 // the host walk and by the device walk must agree.
@@ -788,7 +808,7 @@ extern "C" size_t zstdgpu_batch_decode(zstdgpu_batch* B, const void* devSrc, voi
     if (prof) hipEventRecord(B->ev[4], s);
     launch_checksum(p, s);
     if (prof) { hipEventRecord(B->ev[5], s); B->evRecorded = true; }
-    B->lastStream = s;
+    B->lastStream = s; B->launched = true;
 #ifdef ZG_STAMPS
     {   // diagnostic build: print where the sequence stage spends its cycles
         hipStreamSynchronize(s);
@@ -916,7 +936,7 @@ extern "C" size_t zstdgpu_batch_copyLiterals(zstdgpu_batch* B, const void* devSr
 }
 
 extern "C" size_t zstdgpu_batch_copySequences(zstdgpu_batch* B, uint32_t bi, uint32_t* triples, size_t tripleCapacity)
-{
+try {
     if (!B || bi >= B->nBlocks || !set_device(B->ctx) || !mirror(B)) return mkerr(E_generic);
     if (hipStreamSynchronize(B->lastStream) != hipSuccess) return mkerr(E_generic);
     const DevBlock& d = B->hBlocks[bi];
@@ -941,6 +961,7 @@ extern "C" size_t zstdgpu_batch_copySequences(zstdgpu_batch* B, uint32_t bi, uin
     }
     return st.seqValid;
 }
+catch (...) { return mkerr(E_memory_allocation); }      // the C ABI never throws (std::bad_alloc from the host containers)
 
 // ===================================================================== one-shot drop-ins
 namespace {
@@ -957,7 +978,7 @@ bool ensure(uint8_t*& p, size_t& cap, size_t need)
 
 // ZSTD_decompressMultiFrame (zstd_decompressf.pas:836-942) over the batched device path.
 size_t decompress_multi(zstdgpu_ctx* ctx, void* dst, size_t dstCapacity, const void* srcv, size_t srcSize, const zstdgpu_ddict* ddict)
-{
+try {
     if (!ctx || !set_device(ctx)) return mkerr(E_generic);
     if (ddict && ddict->status) return mkerr(ddict->status);
     const uint8_t* const src = (const uint8_t*)srcv;
@@ -1024,6 +1045,8 @@ size_t decompress_multi(zstdgpu_ctx* ctx, void* dst, size_t dstCapacity, const v
         if (rc) return rc;
         for (uint32_t k = 0; k < n; k++) {
             if (st[k].errorCode) {
+                // as in the reference, the frames decoded before the failing one have reached dst
+                if (produced) hipMemcpy(dst, ctx->dDst, produced, hipMemcpyDeviceToHost);
                 if (st[k].errorCode == E_prefix_unknown && (i + k) > 0) return mkerr(E_srcSize_wrong);
                 return mkerr(st[k].errorCode);
             }
@@ -1031,10 +1054,11 @@ size_t decompress_multi(zstdgpu_ctx* ctx, void* dst, size_t dstCapacity, const v
         }
         i = j;
     }
-    if (tailErr) return tailErr;
     if (produced && hipMemcpy(dst, ctx->dDst, produced, hipMemcpyDeviceToHost) != hipSuccess) return mkerr(E_generic);
+    if (tailErr) return tailErr;
     return produced;
 }
+catch (...) { return mkerr(E_memory_allocation); }      // the C ABI never throws (std::bad_alloc from the host containers)
 
 }  // namespace
 
@@ -1071,37 +1095,49 @@ struct zstdgpu_dstream {
     size_t want = 5;          // bytes of `in` needed before the next decision (ZSTD_startingInputLength to begin with)
     size_t cursor = 0;        // offset of the next block header in `in` (0: frame header not seen yet)
     size_t blocks = 0;        // blocks seen
-    bool checksum = false, skippable = false, lastSeen = false;
+    bool checksum = false, skippable = false, lastSeen = false, onePass = false;
     uint64_t contentSize = ZSTDGPU_CONTENTSIZE_UNKNOWN, windowSize = 0;
     size_t outPos = 0;
     bool flushing = false;
     size_t error = 0;         // sticky until the stream is reset
     zstdgpu_outBuffer expected{nullptr, 0, 0};   // ZSTD_d_stableOutBuffer: the output buffer as the last call left it
     bool busy() const { return !in.empty() || flushing; }      // streamStage <> zdss_init
-    void reset() { in.clear(); out.clear(); want = ctx->format ? 1 : 5; cursor = 0; blocks = 0; checksum = skippable = lastSeen = false;
+    void reset() { in.clear(); out.clear(); want = (ctx && ctx->format) ? 1 : 5; cursor = 0; blocks = 0; checksum = skippable = lastSeen = onePass = false;
                    contentSize = ZSTDGPU_CONTENTSIZE_UNKNOWN; windowSize = 0; outPos = 0; flushing = false; error = 0; }
 };
+
+static void stream_detach(zstdgpu_dstream* z) { z->ctx = nullptr; z->error = mkerr(E_stage_wrong); }
 
 extern "C" zstdgpu_dstream* zstdgpu_createDStream(zstdgpu_ctx* ctx)
 {
     if (!ctx) return nullptr;
     zstdgpu_dstream* z = new (std::nothrow) zstdgpu_dstream;
-    if (z) { z->ctx = ctx; z->reset(); ctx->streams.push_back(z); }
+    if (!z) return nullptr;
+    z->ctx = ctx; z->reset();
+    try { ctx->streams.push_back(z); } catch (...) { delete z; return nullptr; }
     return z;
 }
 extern "C" void zstdgpu_freeDStream(zstdgpu_dstream* z)
 {
     if (!z) return;
-    auto& v = z->ctx->streams;
-    v.erase(std::remove(v.begin(), v.end(), z), v.end());
+    if (z->ctx) { auto& v = z->ctx->streams; v.erase(std::remove(v.begin(), v.end(), z), v.end()); }
     delete z;
 }
 // ZSTD_initDStream / ZSTD_initDStream_usingDDict (:1605-1628): start a new stream (session reset + ZSTD_DCtx_refDDict);
 // returns the first input size hint (ZSTD_startingInputLength of the context's format)
-extern "C" size_t zstdgpu_initDStream(zstdgpu_dstream* z) { if (!z) return mkerr(E_generic); z->reset(); z->ctx->refDDict = nullptr; return z->want; }
-extern "C" size_t zstdgpu_initDStream_usingDDict(zstdgpu_dstream* z, const zstdgpu_ddict* ddict) { if (!z) return mkerr(E_generic); z->reset(); z->ctx->refDDict = ddict; return z->want; }
+// The dictionary belongs to the context, which several streams may share here (in the reference a stream is the
+// context): while another stream of the context is inside a frame the dictionary cannot change (stage_wrong).
+static size_t init_stream(zstdgpu_dstream* z, const zstdgpu_ddict* ddict)
+{
+    if (!z || !z->ctx) return mkerr(z ? E_stage_wrong : E_generic);
+    for (auto* o : z->ctx->streams) if (o != z && o->busy() && z->ctx->refDDict != ddict) return mkerr(E_stage_wrong);
+    z->reset(); z->ctx->refDDict = ddict;
+    return z->want;
+}
+extern "C" size_t zstdgpu_initDStream(zstdgpu_dstream* z) { return init_stream(z, nullptr); }
+extern "C" size_t zstdgpu_initDStream_usingDDict(zstdgpu_dstream* z, const zstdgpu_ddict* ddict) { return init_stream(z, ddict); }
 // ZSTD_resetDStream (:1630-1637): forget a half-read frame, keep the dictionary
-extern "C" size_t zstdgpu_resetDStream(zstdgpu_dstream* z) { if (!z) return mkerr(E_generic); z->reset(); return z->want; }
+extern "C" size_t zstdgpu_resetDStream(zstdgpu_dstream* z) { if (!z || !z->ctx) return mkerr(z ? E_stage_wrong : E_generic); z->reset(); return z->want; }
 
 // ---- decoder parameters (zstd_decompressf.pas:1641-1826)
 extern "C" zstdgpu_bounds zstdgpu_dParam_getBounds(zstdgpu_dParameter p)       // ZSTD_dParam_getBounds :1680-1715
@@ -1169,11 +1205,12 @@ extern "C" size_t zstdgpu_DCtx_reset(zstdgpu_ctx* ctx, zstdgpu_ResetDirective re
 }
 
 extern "C" size_t zstdgpu_decompressStream(zstdgpu_dstream* z, zstdgpu_outBuffer* output, zstdgpu_inBuffer* input)
-{
+try {
     if (!z || !output || !input) return mkerr(E_generic);
     if (input->pos > input->size) return mkerr(E_srcSize_wrong);       // :1994-2003
     if (output->pos > output->size) return mkerr(E_dstSize_tooSmall);
     if (z->error) return z->error;
+    if (!z->ctx) return mkerr(E_stage_wrong);
     auto fail = [&](uint32_t code) { z->error = mkerr(code); return z->error; };
     bool const stable = z->ctx->stableOut != 0, magicless = z->ctx->format != 0;
     // ZSTD_checkOutBuffer (:1913-1928): in stable mode the caller must hand the same buffer back once a frame has begun
@@ -1222,7 +1259,7 @@ extern "C" size_t zstdgpu_decompressStream(zstdgpu_dstream* z, zstdgpu_outBuffer
             bool const onePass = fresh && fh.contentSize != ZSTDGPU_CONTENTSIZE_UNKNOWN && output->size - output->pos >= fh.contentSize &&
                                  !iserr(find_frame_size((const uint8_t*)input->src + startPos, input->size - startPos, false));
             if (!onePass && fh.windowSize > z->ctx->maxWindowSize) return fail(E_frameParameter_windowTooLarge);
-            z->checksum = fh.checksumFlag != 0; z->contentSize = fh.contentSize; z->windowSize = fh.windowSize;
+            z->checksum = fh.checksumFlag != 0; z->contentSize = fh.contentSize; z->windowSize = fh.windowSize; z->onePass = onePass;
             z->cursor = fhsize; z->want = fhsize + 3;
             continue;
         }
@@ -1244,16 +1281,24 @@ extern "C" size_t zstdgpu_decompressStream(zstdgpu_dstream* z, zstdgpu_outBuffer
         }
         // the frame is complete: decode it
         {
-            uint64_t const bound = z->contentSize != ZSTDGPU_CONTENTSIZE_UNKNOWN ? z->contentSize : (uint64_t)z->blocks * kBlockSizeMax;
+            // Room for the output: the content size of the header when the caller has itself offered that much (one-pass
+            // case above), else no more than the blocks that arrived can regenerate in a stream -- blockSizeMax each
+            // (:1170); a header that promises more is wrong, and must not make this stream allocate what it names.
+            uint64_t const byBlocks = (uint64_t)z->blocks * (z->windowSize < kBlockSizeMax ? z->windowSize : kBlockSizeMax);
+            uint64_t bound = z->contentSize != ZSTDGPU_CONTENTSIZE_UNKNOWN ? z->contentSize : byBlocks;
+            bool const capped = !z->onePass && bound > byBlocks;
+            if (capped) bound = byBlocks;
             if (bound > 0x7FFFFFFEull) return fail(E_memory_allocation);
             z->out.resize((size_t)bound);
-            size_t const r = decompress_multi(z->ctx, z->out.data(), z->out.size(), p, z->in.size(), z->ctx->refDDict);
+            size_t r = decompress_multi(z->ctx, z->out.data(), z->out.size(), p, z->in.size(), z->ctx->refDDict);
+            if (capped && iserr(r) && zstdgpu_getErrorCode(r) == E_dstSize_tooSmall) r = mkerr(E_corruption);     // some block exceeds blockSizeMax (:1170)
             if (iserr(r)) { z->error = r; return r; }
             z->out.resize(r);
             z->outPos = 0; z->flushing = true;
         }
     }
 }
+catch (...) { return mkerr(E_memory_allocation); }      // the C ABI never throws (std::bad_alloc from the host containers)
 
 // ZSTD_decompress creates and frees its own context per call (zstd_decompressf.pas:977-988)
 extern "C" size_t zstdgpu_decompress(void* dst, size_t dstCapacity, const void* src, size_t srcSize)

@@ -25,6 +25,7 @@ struct zstdgpu_ctx {
     uint32_t stableOut = 0, ignoreChecksum = 0;
     const zstdgpu_ddict* refDDict = nullptr;
     std::vector<zstdgpu_dstream*> streams;        // streams opened on this context
+    std::vector<zstdgpu_ddict*> ddicts;           // dictionaries created on it (they forget it when it is destroyed)
     uint8_t* scratch = nullptr;                   // this device's fixed scratch array (zstdgpu_decode_frames_noalloc)
     uint32_t opts() const { return (format ? zg::kOptMagicless : 0u) | (ignoreChecksum ? zg::kOptIgnoreChecksum : 0u); }
     void reset_parameters() { format = 0; maxWindowSize = (1ull << 27) + 1; stableOut = 0; ignoreChecksum = 0; }
@@ -35,6 +36,7 @@ struct zstdgpu_ddict {
     uint8_t* dBytes = nullptr;     // whole dictionary on the device
     zg::DevDict* dDict = nullptr;
     uint32_t size = 0, dictID = 0, hasEntropy = 0, entropySize = 0, status = 0;
+    int device = 0;
 };
 
 
