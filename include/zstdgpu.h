@@ -263,6 +263,11 @@ const char* zstdgpu_stage_kernel_name(int stage);
 /* XXH64 of n device buffers (xxhash.pas:409-488): digests[i] = XXH64(devBase+off[i], len[i], seed 0). */
 size_t zstdgpu_xxh64Batch(zstdgpu_ctx* ctx, const void* devBase, const uint64_t* off, const uint64_t* len,
                           uint32_t n, uint64_t* digests);
+/* The three predefined sequence decoding tables as the sequence kernel builds them (the set_basic arm of
+ * ZSTD_buildSeqTable, decompress/zstd_decompress_block.pas:626-688; the reference holds them as the constants
+ * LL_defaultDTable / OF_defaultDTable / ML_defaultDTable, :29-125): cells[t][64][4] = {nextState, nbAdditionalBits, nbBits,
+ * baseValue}, t = 0 LL (64 cells), 1 OF (32 cells, the rest zero), 2 ML (64 cells). */
+size_t zstdgpu_predefinedTables(zstdgpu_ctx* ctx, uint32_t* cells);
 /* Intermediates of the last launch, copied to host arrays (any may be NULL):
  * literals of compressed blocks as decoded by stage 0 (ZSTD_decodeLiteralsBlock), sequences as
  * decoded by stage 1 with repeat offsets resolved (ZSTD_decodeSequence), per block. */

@@ -36,6 +36,9 @@ def lib():
         for n in ("nSeqs", "litBytes"): getattr(L, "oracle_trace_" + n).argtypes = [vp]; getattr(L, "oracle_trace_" + n).restype = u64
         for n in ("blkLitSize", "blkNbSeq", "blkRegen", "lits", "seqs"):
             getattr(L, "oracle_trace_" + n).argtypes = [vp]; getattr(L, "oracle_trace_" + n).restype = vp
+        L.oracle_default_table.argtypes = [ctypes.c_int, vp, vp, vp, vp]; L.oracle_default_table.restype = ctypes.c_uint
+        L.oracle_set_huf.argtypes = [ctypes.c_int]; L.oracle_set_huf.restype = None
+        L.oracle_set_body.argtypes = [ctypes.c_int]; L.oracle_set_body.restype = None
         L.oracle_decompress_batch.argtypes = [vp, vp, vp, vp, vp, vp, u32]; L.oracle_decompress_batch.restype = sz
         _lib = L
     return _lib
@@ -83,6 +86,29 @@ def decompress_traced(frame: bytes, capacity: int, dictionary: bytes = None):
         return res
     finally:
         L.oracle_trace_free(t)
+
+
+def default_table(which: int):
+    """The oracle's predefined table `which` (0 LL, 1 OF, 2 ML) and code tables:
+    dict(tableLog, cells [n][4] {nextState, nbAdditionalBits, nbBits, baseValue}, base, bits, norm)."""
+    cells = np.zeros((64, 4), dtype=np.uint32); base = np.zeros(53, dtype=np.uint32); bits = np.zeros(53, dtype=np.uint32); norm = np.zeros(53, dtype=np.int32)
+    log = lib().oracle_default_table(which, cells.ctypes.data, base.ctypes.data, bits.ctypes.data, norm.ctypes.data)
+    n = (36, 32, 53)[which]
+    return dict(tableLog=log, cells=cells[: 1 << log].tolist(), base=base[:n].tolist(), bits=bits[:n].tolist(), norm=norm[: (36, 29, 53)[which]].tolist())
+
+
+BODY_AS_ZSTD_148, BODY_ALWAYS_PREFETCHING, BODY_NEVER_PREFETCHING = 0, 1, 2
+
+
+def set_body(policy: int):
+    """Which sequence loop the oracle runs (process-wide): as zstd 1.4.8 dispatches (default, what the fixtures pin), always
+    the prefetching loop (the port as written, zstd_decompress_block.pas:1541), or never."""
+    lib().oracle_set_body(policy)
+
+
+def set_huf(policy: int):
+    """0: the Huffman decoder HUF_selectDecoder picks (default); 1: always the single-symbol decoder."""
+    lib().oracle_set_huf(policy)
 
 
 def xxh64(data: bytes, seed: int = 0) -> int:

@@ -16,12 +16,15 @@
  *
  * Citations are file:line relative to the reference tree.
  *
- * Known, deliberate strictness versus libzstd 1.4.8 (malformed input only):
- *  - a sequence bitstream that runs dry before the last sequence's extra bits
- *    is rejected (1.4.8 keeps decoding from a stale container and accepts,
- *    zstd_decompress_block.pas:1301);
- *  - a 4-stream Huffman literal section whose 4th segment would start past the
- *    end of the literal buffer is rejected.
+ * Malformed input follows the cited routines to the letter wherever they stay
+ * inside their buffers: a bitstream that runs dry keeps returning bits of its
+ * last container (BIT_lookBits / BIT_lookBitsFast, bitstream.pas:300-314), the
+ * double-symbol Huffman decoder is used where HUF_selectDecoder picks it, and
+ * the sequence loop is the one ZSTD_decompressBlock_internal of zstd 1.4.8
+ * selects (the port's :1541 always takes the prefetching loop; oracle_set_body
+ * can force either).  One deliberate difference: a 4-stream Huffman literal
+ * section whose 4th segment would start past the end of the literal buffer is
+ * rejected (the reference would write outside the buffer).
  */
 #include <stdint.h>
 #include <stddef.h>
@@ -136,16 +139,28 @@ static size_t BIT_initDStream(BIT_DStream_t* bitD, const BYTE* src, size_t srcSi
     }
     return srcSize;
 }
-/* bitstream.pas:300-337.  Reads past the stream start (bitsConsumed > 64) return 0 here and are
- * flagged by the callers through BIT_reloadDStream's overflow status. */
-static U64 BIT_lookBits(const BIT_DStream_t* bitD, U32 nbBits)
+/* bitstream.pas:282-337.  Once more bits are asked for than the container holds, both forms keep answering
+ * from the container in hand (shift counts wrap at 64): the first takes bits from where the count points after
+ * wrapping, the second shifts zeros in from below.  Neither touches memory. */
+static U64 BIT_lookBits(const BIT_DStream_t* bitD, U32 nbBits)          /* BIT_getMiddleBits: shift + mask */
 {
-    if (nbBits == 0) return 0;
-    if (bitD->bitsConsumed >= 64) return 0;
-    return (bitD->bitContainer << bitD->bitsConsumed) >> (64 - nbBits);
+    U32 const start = 64u - bitD->bitsConsumed - nbBits;                /* wraps like the reference's unsigned arithmetic */
+    return (bitD->bitContainer >> (start & 63)) & (((U64)1 << nbBits) - 1);      /* nbBits <= 31 (BIT_mask) */
+}
+static U64 BIT_lookBitsFast(const BIT_DStream_t* bitD, U32 nbBits)      /* only for nbBits >= 1 */
+{
+    return (bitD->bitContainer << (bitD->bitsConsumed & 63)) >> ((64 - nbBits) & 63);
 }
 static void BIT_skipBits(BIT_DStream_t* bitD, U32 nbBits) { bitD->bitsConsumed += nbBits; }
 static U64 BIT_readBits(BIT_DStream_t* bitD, U32 nbBits) { U64 const v = BIT_lookBits(bitD, nbBits); BIT_skipBits(bitD, nbBits); return v; }
+static U64 BIT_readBitsFast(BIT_DStream_t* bitD, U32 nbBits) { U64 const v = BIT_lookBitsFast(bitD, nbBits); BIT_skipBits(bitD, nbBits); return v; }
+/* bitstream.pas:345-354 */
+static BIT_DStream_status BIT_reloadDStreamFast(BIT_DStream_t* bitD)
+{
+    if (bitD->ptr < bitD->limitPtr) return BIT_DStream_overflow;
+    bitD->ptr -= bitD->bitsConsumed >> 3; bitD->bitsConsumed &= 7; bitD->bitContainer = rdLE64(bitD->ptr);
+    return BIT_DStream_unfinished;
+}
 /* bitstream.pas:361-390 */
 static BIT_DStream_status BIT_reloadDStream(BIT_DStream_t* bitD)
 {
@@ -370,12 +385,13 @@ static size_t HUF_readStats(BYTE* huffWeight, size_t hwSize, U32* rankStats, U32
     return iSize + 1;
 }
 
-typedef struct { BYTE byte; BYTE nbBits; } HUF_DEltX1;   /* huf_decompress.pas:41-44 */
-typedef struct { U32 tableLog; HUF_DEltX1 dt[1 << HUF_TABLELOG_MAX]; } HUF_DTable;
+typedef struct { BYTE byte; BYTE nbBits; } HUF_DEltX1;                  /* huf_decompress.pas:41-44 */
+typedef struct { U16 sequence; BYTE nbBits; BYTE length; } HUF_DEltX2;  /* huf_decompress.pas:57-61: one or two symbols (first in the low byte) */
+typedef struct { BYTE symbol; BYTE weight; } sortedSymbol_t;            /* huf_decompress.pas:62-65 */
+/* tableType 0: single-symbol cells, 2^tableLog of them; 1: double-symbol cells, always 2^12 (DTableDesc, huf_decompress.pas:32-37) */
+typedef struct { U32 tableLog; U32 tableType; union { HUF_DEltX1 x1[1 << HUF_TABLELOG_MAX]; HUF_DEltX2 x2[1 << HUF_TABLELOG_MAX]; } dt; } HUF_DTable;
 
-/* huf_decompress.pas:133-285 (single-symbol table).  The X2 double-symbol decoder
- * (huf_decompress.pas:691-1141) regenerates exactly the same bytes and is a speed choice only
- * (HUF_selectDecoder, :1301-1318), so the oracle keeps one decoder. */
+/* huf_decompress.pas:133-285 (single-symbol table) */
 static size_t HUF_readDTableX1(HUF_DTable* DTable, const BYTE* src, size_t srcSize)
 {
     BYTE huffWeight[256];
@@ -383,7 +399,7 @@ static size_t HUF_readDTableX1(HUF_DTable* DTable, const BYTE* src, size_t srcSi
     U32 tableLog = 0, nbSymbols = 0;
     size_t const iSize = HUF_readStats(huffWeight, 256, rankVal, &nbSymbols, &tableLog, src, srcSize);
     if (isErr(iSize)) return iSize;
-    DTable->tableLog = tableLog;
+    DTable->tableLog = tableLog; DTable->tableType = 0;
     { U32 n, nextRankStart = 0;
       for (n = 1; n < tableLog + 1; n++) { U32 const current = nextRankStart; nextRankStart += rankVal[n] << (n - 1); rankVal[n] = current; } }
     { U32 n;
@@ -392,22 +408,23 @@ static size_t HUF_readDTableX1(HUF_DTable* DTable, const BYTE* src, size_t srcSi
           U32 const length = (1U << w) >> 1;
           U32 u;
           HUF_DEltX1 D; D.byte = (BYTE)n; D.nbBits = (BYTE)(tableLog + 1 - w);
-          for (u = rankVal[w]; u < rankVal[w] + length; u++) DTable->dt[u] = D;
+          for (u = rankVal[w]; u < rankVal[w] + length; u++) DTable->dt.x1[u] = D;
           rankVal[w] += length;
       } }
     return iSize;
 }
 
-/* huf_decompress.pas:292-350 : decode one backward stream until the segment is full */
+/* huf_decompress.pas:292-350 : decode one backward stream until the segment is full.  (The reference unrolls by four
+ * with a reload per group; a reload per symbol reads the same bits, and a stream that over-consumes fails either way.) */
 static size_t HUF_decodeStreamX1(BYTE* p, BYTE* const pEnd, const BYTE* src, size_t srcSize, const HUF_DTable* DTable)
 {
     BIT_DStream_t bitD;
     U32 const dtLog = DTable->tableLog;
     { size_t const e = BIT_initDStream(&bitD, src, srcSize); if (isErr(e)) return e; }
     while (p < pEnd) {
-        size_t const val = (size_t)BIT_lookBits(&bitD, dtLog);
-        *p++ = DTable->dt[val].byte;
-        BIT_skipBits(&bitD, DTable->dt[val].nbBits);
+        size_t const val = (size_t)BIT_lookBitsFast(&bitD, dtLog);      /* HUF_decodeSymbolX1 :292-299 */
+        *p++ = DTable->dt.x1[val].byte;
+        BIT_skipBits(&bitD, DTable->dt.x1[val].nbBits);
         BIT_reloadDStream(&bitD);
     }
     BIT_reloadDStream(&bitD);
@@ -449,6 +466,245 @@ static size_t HUF_decompress4X1_usingDTable(BYTE* dst, size_t dstSize, const BYT
         e = HUF_decodeStreamX1(opStart4, oend,     istart4, length4, DTable); if (isErr(e)) return ERR(corruption_detected);
         return dstSize;
     }
+}
+
+/* ---- double-symbol decoder (huf_decompress.pas:691-1141) ---- */
+/* huf_decompress.pas:691-738 */
+static void HUF_fillDTableX2Level2(HUF_DEltX2* DTable, U32 sizeLog, const U32 consumed, const U32* rankValOrigin, const int minWeight,
+                                   const sortedSymbol_t* sortedSymbols, const U32 sortedListSize, U32 nbBitsBaseline, U16 baseSeq)
+{
+    HUF_DEltX2 DElt;
+    U32 rankVal[HUF_TABLELOG_MAX + 1];
+    U32 s;
+    memcpy(rankVal, rankValOrigin, sizeof(rankVal));
+    if (minWeight > 1) {     /* cells whose second symbol would not fit: the first symbol alone */
+        U32 i, skipSize = rankVal[minWeight];
+        DElt.sequence = baseSeq; DElt.nbBits = (BYTE)consumed; DElt.length = 1;
+        for (i = 0; i < skipSize; i++) DTable[i] = DElt;
+    }
+    for (s = 0; s < sortedListSize; s++) {
+        const U32 symbol = sortedSymbols[s].symbol;
+        const U32 weight = sortedSymbols[s].weight;
+        const U32 nbBits = nbBitsBaseline - weight;
+        const U32 length = 1U << (sizeLog - nbBits);
+        const U32 start = rankVal[weight];
+        U32 i = start;
+        const U32 end = start + length;
+        DElt.sequence = (U16)(baseSeq + (symbol << 8)); DElt.nbBits = (BYTE)(nbBits + consumed); DElt.length = 2;
+        do { DTable[i++] = DElt; } while (i < end);
+        rankVal[weight] += length;
+    }
+}
+typedef U32 rankValCol_t[HUF_TABLELOG_MAX + 1];
+/* huf_decompress.pas:741-790 */
+static void HUF_fillDTableX2(HUF_DEltX2* DTable, const U32 targetLog, const sortedSymbol_t* sortedList, const U32 sortedListSize,
+                             const U32* rankStart, rankValCol_t* rankValOrigin, const U32 maxWeight, const U32 nbBitsBaseline)
+{
+    U32 rankVal[HUF_TABLELOG_MAX + 1];
+    const int scaleLog = (int)nbBitsBaseline - (int)targetLog;
+    const U32 minBits = nbBitsBaseline - maxWeight;
+    U32 s;
+    memcpy(rankVal, rankValOrigin, sizeof(rankVal));
+    for (s = 0; s < sortedListSize; s++) {
+        const U16 symbol = sortedList[s].symbol;
+        const U32 weight = sortedList[s].weight;
+        const U32 nbBits = nbBitsBaseline - weight;
+        const U32 start = rankVal[weight];
+        const U32 length = 1U << (targetLog - nbBits);
+        if (targetLog - nbBits >= minBits) {   /* enough room for a second symbol */
+            U32 sortedRank;
+            int minWeight = (int)nbBits + scaleLog;
+            if (minWeight < 1) minWeight = 1;
+            sortedRank = rankStart[minWeight];
+            HUF_fillDTableX2Level2(DTable + start, targetLog - nbBits, nbBits, rankValOrigin[nbBits], minWeight,
+                                   sortedList + sortedRank, sortedListSize - sortedRank, nbBitsBaseline, symbol);
+        } else {
+            HUF_DEltX2 DElt; U32 u; const U32 end = start + length;
+            DElt.sequence = symbol; DElt.nbBits = (BYTE)nbBits; DElt.length = 1;
+            for (u = start; u < end; u++) DTable[u] = DElt;
+        }
+        rankVal[weight] += length;
+    }
+}
+/* huf_decompress.pas:796-910 : the table is always 2^maxTableLog = 2^12 cells */
+static size_t HUF_readDTableX2(HUF_DTable* DTable, const BYTE* src, size_t srcSize)
+{
+    U32 tableLog, maxW, sizeOfSort, nbSymbols;
+    U32 const maxTableLog = HUF_TABLELOG_MAX;      /* the decoder context's table: hufTable[0] = HufLog * 0x1000001 (zstd_decompressf.pas:1397) */
+    rankValCol_t rankVal[HUF_TABLELOG_MAX];
+    U32 rankStats[HUF_TABLELOG_MAX + 1];
+    U32 rankStart0[HUF_TABLELOG_MAX + 2];
+    U32* const rankStart = rankStart0 + 1;
+    sortedSymbol_t sortedSymbol[256];
+    BYTE weightList[256];
+    size_t iSize;
+    memset(rankStats, 0, sizeof(rankStats)); memset(rankStart0, 0, sizeof(rankStart0)); memset(rankVal, 0, sizeof(rankVal));
+    iSize = HUF_readStats(weightList, 256, rankStats, &nbSymbols, &tableLog, src, srcSize);
+    if (isErr(iSize)) return iSize;
+    if (tableLog > maxTableLog) return ERR(tableLog_tooLarge);
+    for (maxW = tableLog; rankStats[maxW] == 0; maxW--) {}     /* necessarily finds a solution before 0 */
+    {   U32 w, nextRankStart = 0;
+        for (w = 1; w < maxW + 1; w++) { U32 curr = nextRankStart; nextRankStart += rankStats[w]; rankStart[w] = curr; }
+        rankStart[0] = nextRankStart;      /* put all 0w symbols at the end of sorted list */
+        sizeOfSort = nextRankStart;
+    }
+    {   U32 sidx;
+        for (sidx = 0; sidx < nbSymbols; sidx++) {
+            U32 const w = weightList[sidx];
+            U32 const r = rankStart[w]++;
+            sortedSymbol[r].symbol = (BYTE)sidx; sortedSymbol[r].weight = (BYTE)w;
+        }
+        rankStart[0] = 0;                  /* forget 0w symbols; this is beginning of weight(1) */
+    }
+    {   U32* const rankVal0 = rankVal[0];
+        {   int const rescale = (int)(maxTableLog - tableLog) - 1;   /* tableLog <= maxTableLog */
+            U32 nextRankVal = 0, w;
+            for (w = 1; w < maxW + 1; w++) { U32 curr = nextRankVal; nextRankVal += rankStats[w] << (w + rescale); rankVal0[w] = curr; }
+        }
+        {   U32 const minBits = tableLog + 1 - maxW;
+            U32 consumed;
+            for (consumed = minBits; consumed < maxTableLog - minBits + 1; consumed++) {
+                U32* const rankValPtr = rankVal[consumed];
+                U32 w;
+                for (w = 1; w < maxW + 1; w++) rankValPtr[w] = rankVal0[w] >> consumed;
+            }
+        }
+    }
+    HUF_fillDTableX2(DTable->dt.x2, maxTableLog, sortedSymbol, sizeOfSort, rankStart0, rankVal, maxW, tableLog + 1);
+    DTable->tableLog = maxTableLog; DTable->tableType = 1;
+    return iSize;
+}
+/* huf_decompress.pas:913-921 */
+static U32 HUF_decodeSymbolX2(BYTE* op, BIT_DStream_t* DStream, const HUF_DEltX2* dt, const U32 dtLog)
+{
+    size_t const val = (size_t)BIT_lookBitsFast(DStream, dtLog);
+    op[0] = (BYTE)dt[val].sequence; op[1] = (BYTE)(dt[val].sequence >> 8);       /* always two bytes: the slack is the next segment or the buffer's margin */
+    BIT_skipBits(DStream, dt[val].nbBits);
+    return dt[val].length;
+}
+/* huf_decompress.pas:923-942 */
+static U32 HUF_decodeLastSymbolX2(BYTE* op, BIT_DStream_t* DStream, const HUF_DEltX2* dt, const U32 dtLog)
+{
+    size_t const val = (size_t)BIT_lookBitsFast(DStream, dtLog);
+    op[0] = (BYTE)dt[val].sequence;
+    if (dt[val].length == 1) BIT_skipBits(DStream, dt[val].nbBits);
+    else if (DStream->bitsConsumed < 64) {
+        BIT_skipBits(DStream, dt[val].nbBits);
+        if (DStream->bitsConsumed > 64) DStream->bitsConsumed = 64;    /* the cell's count covers two symbols; only the first was wanted */
+    }
+    return 1;
+}
+/* huf_decompress.pas:944-984 */
+static size_t HUF_decodeStreamX2(BYTE* p, BIT_DStream_t* bitDPtr, BYTE* const pEnd, const HUF_DEltX2* const dt, const U32 dtLog)
+{
+    BYTE* const pStart = p;
+    while ((BIT_reloadDStream(bitDPtr) == BIT_DStream_unfinished) & ((pEnd - p) > 7)) {      /* p < pEnd - 7 */
+        p += HUF_decodeSymbolX2(p, bitDPtr, dt, dtLog);
+        p += HUF_decodeSymbolX2(p, bitDPtr, dt, dtLog);
+        p += HUF_decodeSymbolX2(p, bitDPtr, dt, dtLog);
+        p += HUF_decodeSymbolX2(p, bitDPtr, dt, dtLog);
+    }
+    while ((BIT_reloadDStream(bitDPtr) == BIT_DStream_unfinished) & ((pEnd - p) >= 2)) p += HUF_decodeSymbolX2(p, bitDPtr, dt, dtLog);
+    while ((pEnd - p) >= 2) p += HUF_decodeSymbolX2(p, bitDPtr, dt, dtLog);      /* no need to reload : reached the end of DStream */
+    if (p < pEnd) p += HUF_decodeLastSymbolX2(p, bitDPtr, dt, dtLog);
+    return (size_t)(p - pStart);
+}
+/* huf_decompress.pas:986-1014.  dst must have one byte of slack after dstSize (the literal buffer has 32). */
+static size_t HUF_decompress1X2_usingDTable(BYTE* dst, size_t dstSize, const BYTE* cSrc, size_t cSrcSize, const HUF_DTable* DTable)
+{
+    BIT_DStream_t bitD;
+    { size_t const e = BIT_initDStream(&bitD, cSrc, cSrcSize); if (isErr(e)) return e; }
+    HUF_decodeStreamX2(dst, &bitD, dst + dstSize, DTable->dt.x2, DTable->tableLog);
+    if (!BIT_endOfDStream(&bitD)) return ERR(corruption_detected);
+    return dstSize;
+}
+/* huf_decompress.pas:1016-1141 */
+static size_t HUF_decompress4X2_usingDTable(BYTE* dst, size_t dstSize, const BYTE* cSrc, size_t cSrcSize, const HUF_DTable* DTable)
+{
+    if (cSrcSize < 10) return ERR(corruption_detected);
+    {   const BYTE* const istart = cSrc;
+        BYTE* const ostart = dst;
+        BYTE* const oend = ostart + dstSize;
+        const HUF_DEltX2* const dt = DTable->dt.x2;
+        BIT_DStream_t bitD1, bitD2, bitD3, bitD4;
+        size_t const length1 = rdLE16(istart);
+        size_t const length2 = rdLE16(istart + 2);
+        size_t const length3 = rdLE16(istart + 4);
+        size_t const length4 = cSrcSize - (length1 + length2 + length3 + 6);
+        const BYTE* const istart1 = istart + 6;
+        const BYTE* const istart2 = istart1 + length1;
+        const BYTE* const istart3 = istart2 + length2;
+        const BYTE* const istart4 = istart3 + length3;
+        size_t const segmentSize = (dstSize + 3) / 4;
+        BYTE* const opStart2 = ostart + segmentSize;
+        BYTE* const opStart3 = opStart2 + segmentSize;
+        BYTE* const opStart4 = opStart3 + segmentSize;
+        BYTE *op1 = ostart, *op2 = opStart2, *op3 = opStart3, *op4 = opStart4;
+        U32 endSignal = 1;
+        U32 const dtLog = DTable->tableLog;
+        if (length4 > cSrcSize) return ERR(corruption_detected);
+        if (opStart4 > oend) return ERR(corruption_detected);      /* (deliberate: see the file header) */
+        { size_t const e = BIT_initDStream(&bitD1, istart1, length1); if (isErr(e)) return e; }
+        { size_t const e = BIT_initDStream(&bitD2, istart2, length2); if (isErr(e)) return e; }
+        { size_t const e = BIT_initDStream(&bitD3, istart3, length3); if (isErr(e)) return e; }
+        { size_t const e = BIT_initDStream(&bitD4, istart4, length4); if (isErr(e)) return e; }
+        /* 16-32 symbols per loop (4-8 symbols per stream); olimit = oend - 7 */
+        while (endSignal && (oend - op4) > 7) {
+            int k;
+            for (k = 0; k < 4; k++) {
+                op1 += HUF_decodeSymbolX2(op1, &bitD1, dt, dtLog);
+                op2 += HUF_decodeSymbolX2(op2, &bitD2, dt, dtLog);
+                op3 += HUF_decodeSymbolX2(op3, &bitD3, dt, dtLog);
+                op4 += HUF_decodeSymbolX2(op4, &bitD4, dt, dtLog);
+            }
+            endSignal = (U32)((BIT_reloadDStreamFast(&bitD1) == BIT_DStream_unfinished)
+                            & (BIT_reloadDStreamFast(&bitD2) == BIT_DStream_unfinished)
+                            & (BIT_reloadDStreamFast(&bitD3) == BIT_DStream_unfinished)
+                            & (BIT_reloadDStreamFast(&bitD4) == BIT_DStream_unfinished));
+        }
+        if (op1 > opStart2) return ERR(corruption_detected);
+        if (op2 > opStart3) return ERR(corruption_detected);
+        if (op3 > opStart4) return ERR(corruption_detected);
+        HUF_decodeStreamX2(op1, &bitD1, opStart2, dt, dtLog);
+        HUF_decodeStreamX2(op2, &bitD2, opStart3, dt, dtLog);
+        HUF_decodeStreamX2(op3, &bitD3, opStart4, dt, dtLog);
+        HUF_decodeStreamX2(op4, &bitD4, oend,     dt, dtLog);
+        if (!(BIT_endOfDStream(&bitD1) & BIT_endOfDStream(&bitD2) & BIT_endOfDStream(&bitD3) & BIT_endOfDStream(&bitD4))) return ERR(corruption_detected);
+        return dstSize;
+    }
+}
+/* HUF_selectDecoder and its cost table (huf_decompress.pas:81-100, :1301-1318): 0 = single-symbol, 1 = double-symbol */
+typedef struct { U32 tableTime; U32 decode256Time; } algo_time_t;
+static const algo_time_t algoTime[16][3] = {
+    {{0,0}, {1,1}, {2,2}},  {{0,0}, {1,1}, {2,2}},
+    {{  38,130}, {1313, 74}, {2151, 38}},  {{ 448,128}, {1353, 74}, {2238, 41}},
+    {{ 556,128}, {1353, 74}, {2238, 47}},  {{ 714,128}, {1418, 74}, {2436, 53}},
+    {{ 883,128}, {1437, 74}, {2464, 61}},  {{ 897,128}, {1515, 75}, {2622, 68}},
+    {{ 926,128}, {1613, 75}, {2730, 75}},  {{ 947,128}, {1729, 77}, {3359, 77}},
+    {{1107,128}, {2083, 81}, {4006, 84}},  {{1177,128}, {2379, 87}, {4785, 88}},
+    {{1242,128}, {2415, 93}, {5155, 84}},  {{1349,128}, {2644,106}, {5260,106}},
+    {{1455,128}, {2422,124}, {4174,124}},  {{ 722,128}, {1891,145}, {1936,146}},
+};
+static int g_hufPolicy = 0;     /* 0: the selector below decides; 1: always the single-symbol decoder (to show where the choice matters) */
+void oracle_set_huf(int policy) { g_hufPolicy = policy; }
+static U32 HUF_selectDecoder(size_t dstSize, size_t cSrcSize)
+{
+    U32 const Q = (cSrcSize >= dstSize) ? 15 : (U32)(cSrcSize * 16 / dstSize);
+    U32 const D256 = (U32)(dstSize >> 8);
+    U32 const DTime0 = algoTime[Q][0].tableTime + (algoTime[Q][0].decode256Time * D256);
+    U32 DTime1 = algoTime[Q][1].tableTime + (algoTime[Q][1].decode256Time * D256);
+    DTime1 += DTime1 >> 3;      /* advantage to algorithm using less memory, to reduce cache eviction */
+    if (g_hufPolicy == 1) return 0;
+    return DTime1 < DTime0;
+}
+/* the decoder the table in hand was built for (HUF_decompress1X_usingDTable_bmi2 / 4X, huf_decompress.pas:1371, :1404) */
+static size_t HUF_decompress1X_usingDTable(BYTE* dst, size_t dstSize, const BYTE* cSrc, size_t cSrcSize, const HUF_DTable* DTable)
+{
+    return DTable->tableType ? HUF_decompress1X2_usingDTable(dst, dstSize, cSrc, cSrcSize, DTable) : HUF_decompress1X1_usingDTable(dst, dstSize, cSrc, cSrcSize, DTable);
+}
+static size_t HUF_decompress4X_usingDTable(BYTE* dst, size_t dstSize, const BYTE* cSrc, size_t cSrcSize, const HUF_DTable* DTable)
+{
+    return DTable->tableType ? HUF_decompress4X2_usingDTable(dst, dstSize, cSrc, cSrcSize, DTable) : HUF_decompress4X1_usingDTable(dst, dstSize, cSrc, cSrcSize, DTable);
 }
 
 /* ===================== sequence tables (zstd_decompress_block.pas:413-688) ===================== */
@@ -519,6 +775,7 @@ typedef struct {
     const BYTE *prefixStart, *virtualStart, *dictEnd;
     const BYTE* litPtr; size_t litSize;
     U32 dictID;
+    U64 windowSize;            /* fParams.windowSize of the frame being decoded */
     BYTE litBuffer[ZSTD_BLOCKSIZE_MAX + WILDCOPY_OVERLENGTH];
     oracle_trace* trace;
     U32 magicless;             /* ZSTD_d_format = ZSTD_f_zstd1_magicless (zstd.pas:416-417) */
@@ -595,24 +852,27 @@ static size_t ZSTD_decodeLiteralsBlock(DCtx* dctx, const BYTE* src, size_t srcSi
                 if (litSize > ZSTD_BLOCKSIZE_MAX) return ERR(corruption_detected);
                 if (litCSize + lhSize > srcSize) return ERR(corruption_detected);
                 if (litEncType == 3) {
-                    /* huf_decompress.pas:1371 / :1404 */
+                    /* huf_decompress.pas:1371 / :1404 : the decoder the stored table was built for */
                     hufSuccess = singleStream
-                        ? HUF_decompress1X1_usingDTable(dctx->litBuffer, litSize, istart + lhSize, litCSize, dctx->HUFptr)
-                        : HUF_decompress4X1_usingDTable(dctx->litBuffer, litSize, istart + lhSize, litCSize, dctx->HUFptr);
+                        ? HUF_decompress1X_usingDTable(dctx->litBuffer, litSize, istart + lhSize, litCSize, dctx->HUFptr)
+                        : HUF_decompress4X_usingDTable(dctx->litBuffer, litSize, istart + lhSize, litCSize, dctx->HUFptr);
                 } else {
-                    /* huf_decompress.pas:1386 / :1416 : read the table, then decode */
+                    /* huf_decompress.pas:1386 (one stream: always the single-symbol decoder) / :1416 (four streams:
+                     * HUF_selectDecoder): read the table, then decode */
                     const BYTE* cSrc = istart + lhSize; size_t cSrcSize = litCSize;
                     if (!singleStream && litSize == 0) hufSuccess = ERR(dstSize_tooSmall);
                     else if (!singleStream && cSrcSize == 0) hufSuccess = ERR(corruption_detected);
                     else {
-                        size_t const hSize = HUF_readDTableX1(&dctx->entropy.hufTable, cSrc, cSrcSize);
+                        U32 const algoNb = singleStream ? 0 : HUF_selectDecoder(litSize, cSrcSize);
+                        size_t const hSize = algoNb ? HUF_readDTableX2(&dctx->entropy.hufTable, cSrc, cSrcSize)
+                                                    : HUF_readDTableX1(&dctx->entropy.hufTable, cSrc, cSrcSize);
                         if (isErr(hSize)) hufSuccess = hSize;
                         else if (hSize >= cSrcSize) hufSuccess = ERR(srcSize_wrong);
                         else {
                             cSrc += hSize; cSrcSize -= hSize;
                             hufSuccess = singleStream
                                 ? HUF_decompress1X1_usingDTable(dctx->litBuffer, litSize, cSrc, cSrcSize, &dctx->entropy.hufTable)
-                                : HUF_decompress4X1_usingDTable(dctx->litBuffer, litSize, cSrc, cSrcSize, &dctx->entropy.hufTable);
+                                : HUF_decompress4X_usingDTable(dctx->litBuffer, litSize, cSrc, cSrcSize, &dctx->entropy.hufTable);
                         }
                     }
                 }
@@ -742,7 +1002,7 @@ static seq_t ZSTD_decodeSequence(seqState_t* seqState)
     BYTE const totalBits = (BYTE)(llBits + mlBits + ofBits);
     {   size_t offset;
         if (ofBits > 1) {
-            offset = ofBase + (size_t)BIT_readBits(&seqState->DStream, ofBits);
+            offset = ofBase + (size_t)BIT_readBitsFast(&seqState->DStream, ofBits);
             seqState->prevOffset[2] = seqState->prevOffset[1];
             seqState->prevOffset[1] = seqState->prevOffset[0];
             seqState->prevOffset[0] = offset;
@@ -752,7 +1012,7 @@ static seq_t ZSTD_decodeSequence(seqState_t* seqState)
                 if (!ll0) offset = seqState->prevOffset[0];
                 else { offset = seqState->prevOffset[1]; seqState->prevOffset[1] = seqState->prevOffset[0]; seqState->prevOffset[0] = offset; }
             } else {
-                offset = ofBase + ll0 + (size_t)BIT_readBits(&seqState->DStream, 1);
+                offset = ofBase + ll0 + (size_t)BIT_readBitsFast(&seqState->DStream, 1);
                 {   size_t temp = (offset == 3) ? seqState->prevOffset[0] - 1 : seqState->prevOffset[offset];
                     temp += !temp;   /* 0 is not valid; input is corrupted; force offset to 1 (:1154, logical not) */
                     if (offset != 1) seqState->prevOffset[2] = seqState->prevOffset[1];
@@ -764,10 +1024,10 @@ static seq_t ZSTD_decodeSequence(seqState_t* seqState)
         seq.offset = offset;
     }
     seq.matchLength = mlBase;
-    if (mlBits > 0) seq.matchLength += (size_t)BIT_readBits(&seqState->DStream, mlBits);
+    if (mlBits > 0) seq.matchLength += (size_t)BIT_readBitsFast(&seqState->DStream, mlBits);
     if (totalBits >= 57 - (LLFSELog + MLFSELog + OffFSELog)) BIT_reloadDStream(&seqState->DStream);   /* :1171-1174 */
     seq.litLength = llBase;
-    if (llBits > 0) seq.litLength += (size_t)BIT_readBits(&seqState->DStream, llBits);
+    if (llBits > 0) seq.litLength += (size_t)BIT_readBitsFast(&seqState->DStream, llBits);
     return seq;
 }
 /* the state update half of ZSTD_decodeSequence (:1220-1225): order LL, ML, OF */
@@ -809,7 +1069,9 @@ static size_t ZSTD_execSequence(BYTE* op, BYTE* const oend, seq_t sequence, cons
     return sequenceLength;
 }
 
-/* zstd_decompress_block.pas:1232-1320 */
+/* zstd_decompress_block.pas:1232-1320 : decode and execute one sequence at a time.  A stream that runs dry is not an
+ * error here: the reads keep answering from the last container, and only a stream that is NOT used up after the last
+ * sequence is rejected (:1301). */
 static size_t ZSTD_decompressSequences(DCtx* dctx, BYTE* dst, size_t maxDstSize, const BYTE* seqStart, size_t seqSize, int nbSeq)
 {
     const BYTE* ip = seqStart;
@@ -822,7 +1084,6 @@ static size_t ZSTD_decompressSequences(DCtx* dctx, BYTE* dst, size_t maxDstSize,
     if (nbSeq) {
         seqState_t seqState;
         size_t error = 0;
-        int overrun = 0;
         dctx->fseEntropy = 1;
         { U32 i; for (i = 0; i < 3; i++) seqState.prevOffset[i] = dctx->entropy.rep[i]; }
         if (isErr(BIT_initDStream(&seqState.DStream, ip, (size_t)(iend - ip)))) return ERR(corruption_detected);
@@ -831,16 +1092,13 @@ static size_t ZSTD_decompressSequences(DCtx* dctx, BYTE* dst, size_t maxDstSize,
         ZSTD_initFseState(&seqState.stateML, &seqState.DStream, dctx->MLTptr);
         for (;;) {
             seq_t const sequence = ZSTD_decodeSequence(&seqState);
-            if (seqState.DStream.bitsConsumed > 64) overrun = 1;   /* extra bits read past the stream start */
             ZSTD_updateStates(&seqState);
             trace_seq(dctx->trace, (U32)sequence.litLength, (U32)sequence.matchLength, (U32)sequence.offset);
-            {   size_t const oneSeqSize = overrun ? ERR(corruption_detected)
-                    : ZSTD_execSequence(op, oend, sequence, &litPtr, litEnd, dctx->prefixStart, dctx->virtualStart, dctx->dictEnd);
-                BIT_DStream_status const st = BIT_reloadDStream(&seqState.DStream);
+            {   size_t const oneSeqSize = ZSTD_execSequence(op, oend, sequence, &litPtr, litEnd, dctx->prefixStart, dctx->virtualStart, dctx->dictEnd);
+                BIT_reloadDStream(&seqState.DStream);
                 if (isErr(oneSeqSize)) { error = oneSeqSize; break; }
                 op += oneSeqSize;
                 if (--nbSeq == 0) break;
-                if (st == BIT_DStream_overflow) overrun = 1;   /* state bits of a non-final sequence ran dry */
             }
         }
         if (isErr(error)) return error;
@@ -855,6 +1113,86 @@ static size_t ZSTD_decompressSequences(DCtx* dctx, BYTE* dst, size_t maxDstSize,
     }
     return (size_t)(op - ostart);
 }
+
+/* zstd_decompress_block.pas:1321-1421 : the loop that decodes four sequences ahead of the one it executes (the
+ * prefetches themselves do nothing to the result).  Its verdicts differ from the loop above on malformed input: it stops
+ * with corruption_detected as soon as the stream has run dry with sequences left to decode, before it executes the
+ * four decoded last, and it does not look at what is left of the stream at the end. */
+static size_t ZSTD_decompressSequencesLong(DCtx* dctx, BYTE* dst, size_t maxDstSize, const BYTE* seqStart, size_t seqSize, int nbSeq)
+{
+#define STORED_SEQS 4
+#define STORED_SEQS_MASK (STORED_SEQS - 1)
+#define ADVANCED_SEQS 4
+    const BYTE* ip = seqStart;
+    const BYTE* const iend = ip + seqSize;
+    BYTE* const ostart = dst;
+    BYTE* const oend = ostart + maxDstSize;
+    BYTE* op = ostart;
+    const BYTE* litPtr = dctx->litPtr;
+    const BYTE* const litEnd = litPtr + dctx->litSize;
+    if (nbSeq) {
+        seq_t sequences[STORED_SEQS];
+        int const seqAdvance = nbSeq < ADVANCED_SEQS ? nbSeq : ADVANCED_SEQS;
+        seqState_t seqState;
+        int seqNb;
+        dctx->fseEntropy = 1;
+        { U32 i; for (i = 0; i < 3; i++) seqState.prevOffset[i] = dctx->entropy.rep[i]; }
+        if (isErr(BIT_initDStream(&seqState.DStream, ip, (size_t)(iend - ip)))) return ERR(corruption_detected);
+        ZSTD_initFseState(&seqState.stateLL, &seqState.DStream, dctx->LLTptr);
+        ZSTD_initFseState(&seqState.stateOffb, &seqState.DStream, dctx->OFTptr);
+        ZSTD_initFseState(&seqState.stateML, &seqState.DStream, dctx->MLTptr);
+        for (seqNb = 0; (BIT_reloadDStream(&seqState.DStream) <= BIT_DStream_completed) && (seqNb < seqAdvance); seqNb++) {
+            sequences[seqNb] = ZSTD_decodeSequence(&seqState);
+            ZSTD_updateStates(&seqState);
+            trace_seq(dctx->trace, (U32)sequences[seqNb].litLength, (U32)sequences[seqNb].matchLength, (U32)sequences[seqNb].offset);
+        }
+        if (seqNb < seqAdvance) return ERR(corruption_detected);
+        for (; (BIT_reloadDStream(&seqState.DStream) <= BIT_DStream_completed) && (seqNb < nbSeq); seqNb++) {
+            seq_t const sequence = ZSTD_decodeSequence(&seqState);
+            ZSTD_updateStates(&seqState);
+            trace_seq(dctx->trace, (U32)sequence.litLength, (U32)sequence.matchLength, (U32)sequence.offset);
+            {   size_t const oneSeqSize = ZSTD_execSequence(op, oend, sequences[(seqNb - ADVANCED_SEQS) & STORED_SEQS_MASK], &litPtr, litEnd,
+                                                            dctx->prefixStart, dctx->virtualStart, dctx->dictEnd);
+                if (isErr(oneSeqSize)) return oneSeqSize;
+                sequences[seqNb & STORED_SEQS_MASK] = sequence;
+                op += oneSeqSize;
+            }
+        }
+        if (seqNb < nbSeq) return ERR(corruption_detected);
+        seqNb -= seqAdvance;
+        for (; seqNb < nbSeq; seqNb++) {
+            size_t const oneSeqSize = ZSTD_execSequence(op, oend, sequences[seqNb & STORED_SEQS_MASK], &litPtr, litEnd,
+                                                        dctx->prefixStart, dctx->virtualStart, dctx->dictEnd);
+            if (isErr(oneSeqSize)) return oneSeqSize;
+            op += oneSeqSize;
+        }
+        { U32 i; for (i = 0; i < 3; i++) dctx->entropy.rep[i] = (U32)seqState.prevOffset[i]; }
+    }
+    {   size_t const lastLLSize = (size_t)(litEnd - litPtr);
+        if (lastLLSize > (size_t)(oend - op)) return ERR(dstSize_tooSmall);
+        if (lastLLSize) memcpy(op, litPtr, lastLLSize);
+        op += lastLLSize;
+    }
+    return (size_t)(op - ostart);
+}
+
+/* zstd_decompress_block.pas:1460-1488 */
+static U32 ZSTD_getLongOffsetsShare(const SeqTable* offTable)
+{
+    U32 const tableLog = offTable->tableLog;
+    U32 const max = 1U << tableLog;
+    U32 u, total = 0;
+    for (u = 0; u < max; u++) if (offTable->cells[u].nbAdditionalBits > 22) total += 1;
+    total <<= (OffFSELog - tableLog);      /* scale to OffFSELog */
+    return total;
+}
+
+/* Which of the two loops runs.  0: as zstd 1.4.8's ZSTD_decompressBlock_internal chooses -- the prefetching loop only
+ * for frames with a window above 2^24 whose offset table has a share of long offsets of at least 7/256, and more than
+ * 4 sequences (this is the behaviour the libzstd-made fixtures pin); 1: always the prefetching loop, as the port's
+ * zstd_decompress_block.pas:1541 is written; 2: never. */
+static int g_bodyPolicy = 0;
+void oracle_set_body(int policy) { g_bodyPolicy = policy; }
 
 /* zstd_decompress_block.pas:1491-1542 */
 static size_t ZSTD_decompressBlock_internal(DCtx* dctx, BYTE* dst, size_t dstCapacity, const BYTE* src, size_t srcSize)
@@ -871,7 +1209,13 @@ static size_t ZSTD_decompressBlock_internal(DCtx* dctx, BYTE* dst, size_t dstCap
         size_t r;
         if (isErr(seqHSize)) return seqHSize;
         ip += seqHSize; srcSize -= seqHSize;
-        r = ZSTD_decompressSequences(dctx, dst, dstCapacity, ip, srcSize, nbSeq);
+        {   int usePrefetchDecoder = 0;      /* (ddictIsCold concerns digested dictionaries only: not on this path) */
+            if (g_bodyPolicy == 1) usePrefetchDecoder = 1;
+            else if (g_bodyPolicy == 0 && dctx->windowSize > (1ULL << 24) && nbSeq > ADVANCED_SEQS)
+                usePrefetchDecoder = ZSTD_getLongOffsetsShare(dctx->OFTptr) >= 7;
+            r = usePrefetchDecoder ? ZSTD_decompressSequencesLong(dctx, dst, dstCapacity, ip, srcSize, nbSeq)
+                                   : ZSTD_decompressSequences(dctx, dst, dstCapacity, ip, srcSize, nbSeq);
+        }
         if (dctx->trace && !isErr(r)) dctx->trace->blkRegen[dctx->trace->nBlocks - 1] = (U32)r;
         return r;
     }
@@ -989,7 +1333,8 @@ static size_t ZSTD_loadDEntropy(EntropyTables* entropy, const BYTE* dict, size_t
     const BYTE* const dictEnd = dictPtr + dictSize;
     if (dictSize <= 8) return ERR(dictionary_corrupted);
     dictPtr += 8;
-    {   size_t const hSize = HUF_readDTableX1(&entropy->hufTable, dictPtr, (size_t)(dictEnd - dictPtr));
+    {   size_t const hSize = g_hufPolicy == 1 ? HUF_readDTableX1(&entropy->hufTable, dictPtr, (size_t)(dictEnd - dictPtr))
+                                              : HUF_readDTableX2(&entropy->hufTable, dictPtr, (size_t)(dictEnd - dictPtr));   /* always the double-symbol form (:1288) */
         if (isErr(hSize)) return ERR(dictionary_corrupted);
         dictPtr += hSize;
     }
@@ -1087,6 +1432,7 @@ static size_t ZSTD_decompressFrame(DCtx* dctx, BYTE* dst, size_t dstCapacity, co
             if (isErr(r)) return r;
             if (r > 0) return ERR(srcSize_wrong);
             if (fh.dictID && (dctx->dictID != fh.dictID)) return ERR(dictionary_wrong);
+            dctx->windowSize = fh.windowSize;
         }
         ip += frameHeaderSize; remainingSrcSize -= frameHeaderSize;
     }
@@ -1237,6 +1583,26 @@ size_t oracle_findFrameCompressedSize(const void* srcv, size_t srcSize)
         if (zfh.checksumFlag) { if (remainingSize < 4) return ERR(srcSize_wrong); ip += 4; }
         return (size_t)(ip - src);
     }
+}
+
+/* ---- the constant tables in use, for the known-answer check against the reference's own copies
+ * (zstd_decompress_block.pas:29-125, zstd_ddict.pas:23-49, zstd_internal.pas:57-99).
+ * which: 0 LL, 1 OF, 2 ML.  cells: 4 values per cell {nextState, nbAdditionalBits, nbBits, baseValue}; returns the table log.
+ * base / bits / norm receive the code tables and the default distribution (MaxLL+1 / MaxOff+1 resp. 29 / MaxML+1 entries). */
+unsigned oracle_default_table(int which, U32* cells, U32* base, U32* bits, int* norm)
+{
+    const SeqTable* t; const U32 *b, *bt; const S16* nm; U32 n, nNorm, u;
+    oracle_init();
+    if (which == 0) { t = &LL_defaultDTable; b = LL_base; bt = LL_bits; nm = LL_defaultNorm; n = MaxLL + 1; nNorm = MaxLL + 1; }
+    else if (which == 1) { t = &OF_defaultDTable; b = OF_base; bt = OF_bits; nm = OF_defaultNorm; n = MaxOff + 1; nNorm = 29; }
+    else { t = &ML_defaultDTable; b = ML_base; bt = ML_bits; nm = ML_defaultNorm; n = MaxML + 1; nNorm = MaxML + 1; }
+    for (u = 0; u < (1U << t->tableLog); u++) {
+        cells[4 * u] = t->cells[u].nextState; cells[4 * u + 1] = t->cells[u].nbAdditionalBits;
+        cells[4 * u + 2] = t->cells[u].nbBits; cells[4 * u + 3] = t->cells[u].baseValue;
+    }
+    for (u = 0; u < n; u++) { base[u] = b[u]; bits[u] = bt[u]; }
+    for (u = 0; u < nNorm; u++) norm[u] = nm[u];
+    return t->tableLog;
 }
 
 /* ---- traced decode: same result as oracle_decompress_usingDict, plus per-block intermediates ---- */

@@ -84,3 +84,25 @@ PARAM_IDS = [e["name"] for e in PARAM_FRAMES]
 def read_param_frame(e) -> bytes:
     with open(os.path.join(GOLD, "params", e["file"]), "rb") as f:
         return f.read()
+
+
+# damaged frames on which 1.4.8, the port as written and a single-symbol-only decoder disagree (tools/gen_divergent_fixtures.py)
+def load_divergent_manifest():
+    with open(os.path.join(GOLD, "divergent", "manifest.json")) as f:
+        return json.load(f)
+
+
+DIVERGENT_FRAMES = load_divergent_manifest()["frames"]
+DIVERGENT_IDS = [e["name"] for e in DIVERGENT_FRAMES]
+
+
+def read_divergent_frame(e) -> bytes:
+    with open(os.path.join(GOLD, "divergent", e["file"]), "rb") as f:
+        return f.read()
+
+
+def verdict_of(out, err):
+    """(error code, size, sha256) in the shape of the manifests' verdict entries."""
+    if err:
+        return {"error": err}
+    return {"size": len(out), "sha256": hashlib.sha256(out).hexdigest()}

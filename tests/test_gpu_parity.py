@@ -6,7 +6,7 @@ import hashlib
 import numpy as np
 import pytest
 
-from conftest import FRAMES, FRAME_IDS, read_frame, read_dict, regenerate
+from conftest import DIVERGENT_FRAMES, DIVERGENT_IDS, FRAMES, FRAME_IDS, read_divergent_frame, read_frame, read_dict, regenerate, verdict_of
 from oracle import oracle
 from zstd_amd import api
 
@@ -45,6 +45,20 @@ def test_oneshot_matches_oracle_and_manifest(dctx, e):
     if not gerr:
         assert got == want
         assert hashlib.sha256(got).hexdigest() == e["sha256"]
+
+
+@pytest.mark.parametrize("e", DIVERGENT_FRAMES, ids=DIVERGENT_IDS)
+def test_divergent_fixtures_follow_zstd_148(dctx, e):
+    """Damaged frames on which zstd 1.4.8, the port as written and a single-symbol-only decoder disagree
+    (tests/golden/divergent/): the GPU follows 1.4.8 -- stale-container reads of a dry sequence stream, the
+    double-symbol decoder's last-symbol rule -- like the oracle."""
+    fr = read_divergent_frame(e)
+    try:
+        got = verdict_of(api.ZSTD_decompressDCtx(dctx, fr, e["capacity"]), 0)
+    except api.ZstdError as ex:
+        got = verdict_of(None, ex.code)
+    assert got == e["build"]
+    assert got == verdict_of(*oracle.decompress(fr, e["capacity"]))
 
 
 def test_zstd_decompress_creates_its_own_context():
@@ -151,6 +165,19 @@ def test_stage_intermediates_match_oracle_trace(dctx, name):
         lpos += info["litSize"]
         spos += info["nbSeq"]
     b.close()
+
+
+def test_predefined_tables_equal_the_reference_constants(dctx):
+    """The reference-held known answers (tests/golden/ref_default_tables.json): the sequence kernel's predefined tables,
+    built by its own description parser and cooperative table builder, equal the reference's literal cells."""
+    import json
+    import os
+    from conftest import GOLD
+    ref = json.load(open(os.path.join(GOLD, "ref_default_tables.json")))
+    got = api.predefined_tables(dctx)
+    assert got[0] == ref["LL_defaultDTable"]["cells"]
+    assert got[1] == ref["OF_defaultDTable"]["cells"]
+    assert got[2] == ref["ML_defaultDTable"]["cells"]
 
 
 def test_xxh64_stage(dctx):

@@ -4,7 +4,7 @@ import hashlib
 
 import pytest
 
-from conftest import FRAMES, FRAME_IDS, read_frame, read_dict, regenerate
+from conftest import DIVERGENT_FRAMES, DIVERGENT_IDS, read_divergent_frame, verdict_of, FRAMES, FRAME_IDS, read_frame, read_dict, regenerate
 from oracle import oracle
 
 
@@ -61,3 +61,40 @@ def test_oracle_matches_libzstd_under_decoder_parameters(e):
     assert err == e.get("error", 0)
     if not err:
         assert len(out) == e["size"] and hashlib.sha256(out).hexdigest() == e["sha256"]
+
+
+def test_predefined_tables_equal_the_reference_constants():
+    """The only known-answer data the reference holds for this path: its three predefined sequence decoding tables and the
+    code tables (tests/golden/ref_default_tables.json, extracted by tools/extract_ref_tables.py).  The oracle builds its
+    tables from the default distributions; they must come out as the reference's literal cells."""
+    import json
+    import os
+    from conftest import GOLD
+    ref = json.load(open(os.path.join(GOLD, "ref_default_tables.json")))
+    for which, name, base, bits, norm in ((0, "LL_defaultDTable", "LL_base", "LL_bits", "LL_defaultNorm"),
+                                          (1, "OF_defaultDTable", "OF_base", "OF_bits", "OF_defaultNorm"),
+                                          (2, "ML_defaultDTable", "ML_base", "ML_bits", "ML_defaultNorm")):
+        t = oracle.default_table(which)
+        assert t["tableLog"] == ref[name]["tableLog"]
+        assert t["cells"] == ref[name]["cells"], name
+        assert t["base"] == ref[base] and t["bits"] == ref[bits] and t["norm"] == ref[norm]
+
+
+@pytest.mark.parametrize("e", DIVERGENT_FRAMES, ids=DIVERGENT_IDS)
+def test_divergent_fixtures_every_verdict(e):
+    """Damaged frames on which the candidates for "the reference" disagree: the oracle follows zstd 1.4.8 (as 1.4.8
+    dispatches, no pre-1.0 formats); with the port's always-prefetching sequence loop, or with the single-symbol Huffman
+    decoder forced, it reproduces the other recorded verdicts."""
+    fr = read_divergent_frame(e)
+    try:
+        assert verdict_of(*oracle.decompress(fr, e["capacity"])) == e["build"]
+        if e["class"] != "legacy_magic":
+            assert e["build"] == e["zstd148"]
+        oracle.set_body(oracle.BODY_ALWAYS_PREFETCHING)
+        assert verdict_of(*oracle.decompress(fr, e["capacity"])) == e["as_written"]
+        oracle.set_body(oracle.BODY_AS_ZSTD_148)
+        oracle.set_huf(1)
+        assert verdict_of(*oracle.decompress(fr, e["capacity"])) == e["x1_only"]
+    finally:
+        oracle.set_body(oracle.BODY_AS_ZSTD_148)
+        oracle.set_huf(0)

@@ -71,7 +71,7 @@ EXPORTS = (
     "zstdgpu_batch_decode", "zstdgpu_batch_status", "zstdgpu_batch_nFrames", "zstdgpu_batch_nBlocks", "zstdgpu_batch_srcBytes",
     "zstdgpu_batch_scratchBytes", "zstdgpu_batch_set_profiling", "zstdgpu_batch_stage_ms", "zstdgpu_stage_kernel_name",
     "zstdgpu_decode_frames_noalloc",
-    "zstdgpu_xxh64Batch", "zstdgpu_batch_blockInfo", "zstdgpu_batch_copyLiterals", "zstdgpu_batch_copySequences",
+    "zstdgpu_xxh64Batch", "zstdgpu_predefinedTables", "zstdgpu_batch_blockInfo", "zstdgpu_batch_copyLiterals", "zstdgpu_batch_copySequences",
 )
 
 
@@ -158,6 +158,7 @@ def lib():
     proto("zstdgpu_batch_stage_ms", sz, vp, P(ctypes.c_float))
     proto("zstdgpu_stage_kernel_name", ctypes.c_char_p, ci)
     proto("zstdgpu_xxh64Batch", sz, vp, vp, vp, vp, u32, vp)
+    proto("zstdgpu_predefinedTables", sz, vp, vp)
     proto("zstdgpu_batch_blockInfo", sz, vp, u32, P(u32), P(u32), P(u64), P(u32))
     proto("zstdgpu_batch_copyLiterals", sz, vp, vp, u32, vp, sz)
     proto("zstdgpu_batch_copySequences", sz, vp, u32, vp, sz)
@@ -425,6 +426,13 @@ def xxh64_batch(dctx: DCtx, dev_base_ptr: int, offsets, lengths) -> np.ndarray:
     out = np.zeros(len(off), dtype=np.uint64)
     _check(lib().zstdgpu_xxh64Batch(dctx.h, dev_base_ptr, off.ctypes.data, ln.ctypes.data, len(off), out.ctypes.data))
     return out
+
+
+def predefined_tables(dctx: DCtx):
+    """The GPU's predefined LL / OF / ML decoding tables: three lists of [nextState, nbAdditionalBits, nbBits, baseValue] cells."""
+    out = np.zeros((3, 64, 4), dtype=np.uint32)
+    _check(lib().zstdgpu_predefinedTables(dctx.h, out.ctypes.data))
+    return [out[0].tolist(), out[1][:32].tolist(), out[2].tolist()]
 
 
 def pack_frames(frames, capacities=None, align: int = 16):

@@ -1461,6 +1461,42 @@ DEVI void grp_build_seq_table(int t, uint32_t* cells, const int16_t* norm, uint3
     lds_sync();
 }
 
+// Stage hook: the three predefined tables (ZSTD_buildSeqTable's set_basic arm; the reference holds them as constants,
+// zstd_decompress_block.pas:29-125) exactly as the sequence kernel builds them -- same description parser, same
+// cooperative builder -- unpacked to {nextState, nbAdditionalBits, nbBits, baseValue}: out[t][cell][4], t = LL, OF, ML.
+__global__ __launch_bounds__(64) void k_basic_tables(uint32_t* out)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t cells[64];
+    __shared__ __attribute__((aligned(16))) int16_t norm[64];
+    __shared__ __attribute__((aligned(16))) uint8_t bscr[kGrpBuildScratch];
+    __shared__ uint8_t sLLbits[36], sMLbits[53];
+    __shared__ uint32_t note[3];
+    uint32_t const lane = threadIdx.x;
+    if (lane < 36) sLLbits[lane] = c_LL_bits[lane];
+    if (lane < 53) sMLbits[lane] = c_ML_bits[lane];
+    wave_sync();
+    if (lane >= 16) return;
+    for (int t = 0; t < 3; t++) {
+        if (lane == 0) {
+            uint32_t kind = TK_FAIL, maxSV = 0, lg = 0;
+            dev_parse_desc(t, SET_BASIC, (const uint8_t*)nullptr, 0u, cells, norm, kind, maxSV, lg, sLLbits, sMLbits);
+            note[0] = kind; note[1] = maxSV; note[2] = lg;
+        }
+        lds_sync();
+        uint32_t const maxSV = note[1], lg = note[2];
+        grp_build_seq_table(t, cells, norm, maxSV, lg, bscr, lane, sLLbits, sMLbits);
+        for (uint32_t u = lane; u < 64; u += 16) {
+            uint32_t const c = cells[u];
+            uint32_t const add = cell_addBits(t, c);
+            uint32_t const base = t == T_LL ? c_LL_base[cell_llCode(c)] : t == T_ML ? c_ML_base[cell_mlCode(c)] : (add < 2 ? add : (1u << add) - 3u);
+            uint32_t* const o = out + 4 * (64 * t + u);
+            bool const live = u < (1u << lg);
+            o[0] = live ? (c & 0x1FFu) : 0u; o[1] = live ? add : 0u; o[2] = live ? cell_nbBits(c) : 0u; o[3] = live ? base : 0u;
+        }
+        lds_sync();
+    }
+}
+
 // ---------------------------------------------------------------- stage 1: sequences
 // value of the lane D places lower in the same row of 16 lanes (own value where there is none)
 template <int D>
@@ -2699,6 +2735,10 @@ void launch_checksum(const BatchParams& p, void* stream)
 void launch_digest_dict(const uint8_t* devDict, uint32_t dictSize, DevDict* out, void* stream)
 {
     hipLaunchKernelGGL(k_digest_dict, dim3(1), dim3(64), 0, (hipStream_t)stream, devDict, dictSize, out);
+}
+void launch_basic_tables(uint32_t* out, void* stream)
+{
+    hipLaunchKernelGGL(k_basic_tables, dim3(1), dim3(64), 0, (hipStream_t)stream, out);
 }
 void launch_xxh64(const uint8_t* base, const uint64_t* off, const uint64_t* len, uint32_t n, uint64_t* out, void* stream)
 {

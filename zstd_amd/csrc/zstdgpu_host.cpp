@@ -901,6 +901,18 @@ extern "C" size_t zstdgpu_xxh64Batch(zstdgpu_ctx* ctx, const void* devBase, cons
     return rc;
 }
 
+extern "C" size_t zstdgpu_predefinedTables(zstdgpu_ctx* ctx, uint32_t* cells)
+{
+    if (!ctx || !cells || !set_device(ctx)) return mkerr(E_generic);
+    uint32_t* d = nullptr;
+    uint64_t acct = 0;
+    if (!dalloc(d, 3 * 64 * 4, acct)) return mkerr(E_memory_allocation);
+    launch_basic_tables(d, nullptr);
+    size_t const rc = hipMemcpy(cells, d, 3 * 64 * 4 * sizeof(uint32_t), hipMemcpyDeviceToHost) == hipSuccess ? 0 : mkerr(E_generic);
+    hipFree(d);
+    return rc;
+}
+
 extern "C" size_t zstdgpu_batch_blockInfo(zstdgpu_batch* B, uint32_t bi, uint32_t* litSize, uint32_t* nbSeq, uint64_t* regenSize, uint32_t* errorCode)
 {
     if (!B || bi >= B->nBlocks || !set_device(B->ctx) || !mirror(B)) return mkerr(E_generic);
