@@ -539,6 +539,23 @@ struct HufGeo {
     DEVI uint32_t oCnt(uint32_t k) const { return k < 3 ? seg : lastCnt; }
 };
 
+// HUF_selectDecoder and the two columns of its cost table that it reads (huf_decompress.pas:81-100, :1301-1318):
+// true when the reference would decode (dstSize, cSrcSize) with the double-symbol decoder.  The bytes are the same
+// either way; what differs is the verdict on a damaged stream at its last symbol (see the serial decode below).
+__constant__ uint16_t c_algoTime[16][4] = {     // {tableTime, decode256Time} of the single-symbol and of the double-symbol decoder
+    {0, 0, 1, 1}, {0, 0, 1, 1}, {38, 130, 1313, 74}, {448, 128, 1353, 74}, {556, 128, 1353, 74}, {714, 128, 1418, 74},
+    {883, 128, 1437, 74}, {897, 128, 1515, 75}, {926, 128, 1613, 75}, {947, 128, 1729, 77}, {1107, 128, 2083, 81},
+    {1177, 128, 2379, 87}, {1242, 128, 2415, 93}, {1349, 128, 2644, 106}, {1455, 128, 2422, 124}, {722, 128, 1891, 145}};
+DEVI bool huf_select_x2(uint32_t dstSize, uint32_t cSrcSize)
+{
+    uint32_t const Q = cSrcSize >= dstSize ? 15u : cSrcSize * 16u / dstSize;
+    uint32_t const D256 = dstSize >> 8;
+    uint32_t const t0 = c_algoTime[Q][0] + c_algoTime[Q][1] * D256;
+    uint32_t t1 = c_algoTime[Q][2] + c_algoTime[Q][3] * D256;
+    t1 += t1 >> 3;
+    return t1 < t0;
+}
+
 // flush up to kHufRound decoded bytes per stream from the LDS stages to the literal buffer: 32 units, 2 per lane
 DEVI void huf_flush(uint8_t* out, const uint8_t* outStage, const HufGeo& g, uint32_t pr, uint32_t nStreams, uint32_t gl)
 {
@@ -579,6 +596,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
 #endif
     uint32_t err = 0, tableLog = 0, nbSymbols = 0, hSize = 0;
     bool const fromDict = (blk.hufSrc == SRC_DICT);
+    // Which decoder the reference runs on this block's streams: the double-symbol one for a dictionary's table
+    // (zstd_decompressf.pas:1288) and where HUF_selectDecoder picked it for the block that defined the table (four
+    // streams only: a single-stream block always builds the single-symbol table, huf_decompress.pas:1386).
+    bool x2 = fromDict;
+    if (blk.hufSrc >= 0) {
+        uint32_t dSingle = blk.singleStream, dLit = blk.litSize, dC = blk.litCSize;
+        if (blk.hufSrc != (int32_t)b) { const DevBlock* const sbp = p.blocks + blk.hufSrc; dSingle = sbp->singleStream; dLit = sbp->litSize; dC = sbp->litCSize; }
+        x2 = !dSingle && dLit != 0 && huf_select_x2(dLit, dC);
+    }
     // The table description (at most 129 bytes) is parsed by one lane; the group first copies it into LDS, with the
     // 8 bytes before it that the backward bit reader may touch (block and literals headers always precede it).
     uint8_t* const hdrStage = tab + 2048;
@@ -1015,6 +1041,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
         }
     }
     uint32_t const maxCntSerial = specDone ? 0u : maxCnt;
+    uint32_t pend = 0;      // serial decode under the double-symbol decoder: see cell_step below
 
     // Input windows: per stream 24 aligned 16-byte units ending just above its unread bits.  A round consumes at most
     // 1536 bits (usually far less); the windows are loaded again only when some stream's window could not feed
@@ -1063,12 +1090,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
 #endif
         // 3. decode up to 128 symbols of my stream, LDS only (HUF_decodeStreamX1, huf_decompress.pas:301-349)
         if (sl < nStreams && !bad && done < myCnt) {
-            uint32_t const n = myCnt - done < kHufRound ? myCnt - done : kHufRound;
+            // (under the double-symbol decoder the stream's last symbol has rules of its own: it is left to the end of the step)
+            uint32_t const myMain = x2 ? myCnt - 1 : myCnt;
+            uint32_t const n = myMain - done < kHufRound ? myMain - done : kHufRound;
             uintptr_t const mywb = sl == 0 ? wb[0] : sl == 1 ? wb[1] : sl == 2 ? wb[2] : wb[3];
             int const Qbase = (int)(8 * (int64_t)((uintptr_t)myStart - mywb));
             uint32_t Q = (uint32_t)(Qbase + bitsLeft);       // >= 1409: a round consumes <= 1536 bits of a window that holds >= 2945
             const uint32_t* const win = inWin + sl * kHufInDw;
             uint32_t* const so = (uint32_t*)(outStage + sl * kHufRound);
+            // The double-symbol decoder takes the symbols in cells of one or two: two when the second code fits in the 12 bits
+            // behind the first (HUF_fillDTableX2, huf_decompress.pas:741-790).  `pend` = length of the code that opened the
+            // cell in progress (0: the next symbol opens one); it decides how the stream's last symbol is judged.
+            auto cell_step = [&](uint32_t len) { bool const second = pend != 0 && pend + len <= 12; pend = second ? 0u : len; };
             uint32_t i = 0;
             for (; i + 4 <= n; i += 4) {     // 4 symbols (<= 48 bits) per 64-bit peek
                 uint32_t tHi, tLo;
@@ -1083,6 +1116,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
                 pbits += c3 >> 8;
                 so[i >> 2] = (c0 & 0xFF) | ((c1 & 0xFF) << 8) | ((c2 & 0xFF) << 16) | (c3 << 24);
                 Q -= pbits;
+                if (x2) { cell_step(c0 >> 8); cell_step(c1 >> 8); cell_step(c2 >> 8); cell_step(c3 >> 8); }
             }
             for (; i < n; i++) {
                 uint32_t tHi, tLo;
@@ -1090,9 +1124,46 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
                 uint32_t const c0 = cells[tHi >> shift];
                 ((uint8_t*)so)[i] = (uint8_t)c0;
                 Q -= c0 >> 8;
+                if (x2) cell_step(c0 >> 8);
+            }
+            done += n;
+            if (x2 && done == myMain && n < kHufRound) {
+                // The stream's last symbol under the double-symbol decoder, worked out on the single-symbol table.  r = bits of
+                // the stream not yet read; look-ups past them see zeros.
+                //  - It closes a cell of two (the cell was looked up when its first code was read): an ordinary symbol, the
+                //    stream must end with its code.
+                //  - It opens a cell: HUF_decodeLastSymbolX2 (huf_decompress.pas:923-942) writes the cell's first symbol; a
+                //    cell of one consumes its code as usual; a cell of two consumes both codes unless the stream is used
+                //    up already, and a count that then passes the end of the stream is set back to it -- such a stream ends
+                //    well whatever the codes were.  With nothing left (r = 0) the look-up's shift count wraps
+                //    (bitstream.pas:310-314) and the 12 bits are the top of the container in hand: the stream's first 8 bytes.
+                int const r = (int)Q - Qbase;
+                uint32_t tHi, tLo;
+                peek64(win, Q, tHi, tLo);
+                uint32_t wz = tHi >> 20;
+                if (r < 12) wz &= r > 0 ? ~((1u << (12 - r)) - 1u) : 0u;
+                uint32_t const cZ = cells[wz >> (12 - tableLog)], nZ = cZ >> 8;
+                bool fine;
+                uint32_t byte;
+                if (pend != 0 && pend + nZ <= 12) { byte = cZ; fine = (int)nZ == r; }
+                else {
+                    uint32_t w12 = wz;
+                    if (r <= 0) {
+                        uint64_t c8 = 0;
+                        for (uint32_t q = 0; q < 8 && q < mySize; q++) c8 |= (uint64_t)myStart[q] << (8 * q);
+                        w12 = (uint32_t)(c8 >> 52);
+                    }
+                    uint32_t const cA = cells[w12 >> (12 - tableLog)], n1 = cA >> 8;
+                    uint32_t const cB = cells[((w12 << n1) & 0xFFFu) >> (12 - tableLog)], n2 = cB >> 8;
+                    bool const two = n1 + n2 <= 12;
+                    fine = r >= 0 && (two ? (r == 0 || (int)(n1 + n2) >= r) : (int)n1 == r);
+                    byte = cA;
+                }
+                ((uint8_t*)so)[n] = (uint8_t)byte;
+                if (fine) Q = (uint32_t)Qbase; else bad = true;
+                done += 1;
             }
             bitsLeft = (int)Q - Qbase;
-            done += n;
         }
         lds_sync();
 #ifdef ZG_STAMPS
@@ -1999,11 +2070,160 @@ __global__ __launch_bounds__(kSeqThreads) void k_sequences(BatchParams p)
             out[nValid] = make_uint4(0, outPos, litPos, 0);      // end record
             st->seqErr = 0;
             st->seqValid = nValid;
+            // A stream that ran dry before the block's last sequence is not an error in the reference: its reads go on
+            // answering from the last container (bitstream.pas:300-314).  Such blocks (damaged input only) are decoded
+            // again, serially and to the letter, by k_sequences_dry.
+            if (nValid < nbSeq) { uint32_t const at = atomicAdd(p.dryList, 1u); p.dryList[1 + at] = b; }
             // after the last sequence the reader must be at (or, through the last state update, past) the stream start (:1301)
             st->tailErr = (nValid == nbSeq && (int)Qend > (int)Qstart) ? (uint32_t)E_corruption : 0u;
             st->regen = (uint64_t)outPos + (litPos <= blk.litSize ? blk.litSize - litPos : 0);
             st->repOut[0] = rep.a; st->repOut[1] = rep.b; st->repOut[2] = rep.c;
         }
+    }
+}
+
+// ---------------------------------------------------------------- stage 1b: sequence streams that run dry
+// BIT_DStream_t to the letter (bitstream.pas:40-51, :206-398): a 64-bit container, a count of consumed bits that may pass
+// 64, and reads that then keep answering from the container in hand (the two read forms wrap differently).
+struct DStreamEmu {
+    const uint8_t* start; const uint8_t* ptr; const uint8_t* limit;
+    uint64_t c; uint32_t consumed;
+    DEVI bool init(const uint8_t* src, uint32_t size)      // false: empty stream or no end mark
+    {
+        start = src; limit = src + 8; c = 0; consumed = 0; ptr = src;
+        if (size < 1) return false;
+        uint32_t const last = src[size - 1];
+        if (size >= 8) { ptr = src + size - 8; c = ld_u64(ptr); consumed = last ? 8 - hb32(last) : 0; }
+        else {
+            for (uint32_t i = 0; i < size; i++) c |= (uint64_t)src[i] << (8 * i);
+            consumed = (last ? 8 - hb32(last) : 0) + (8 - size) * 8;
+        }
+        return last != 0;
+    }
+    DEVI uint32_t look(uint32_t n) const { uint32_t const st = 64u - consumed - n; return (uint32_t)((c >> (st & 63)) & ((1ull << n) - 1)); }      // BIT_lookBits
+    DEVI uint32_t lookFast(uint32_t n) const { return (uint32_t)((c << (consumed & 63)) >> ((64 - n) & 63)); }                                // BIT_lookBitsFast, n >= 1
+    DEVI uint32_t read(uint32_t n) { uint32_t const v = look(n); consumed += n; return v; }
+    DEVI uint32_t readFast(uint32_t n) { uint32_t const v = lookFast(n); consumed += n; return v; }
+    // BIT_reloadDStream: 0 unfinished, 1 end of buffer, 2 completed, 3 overflow
+    DEVI uint32_t reload()
+    {
+        if (consumed > 64) return 3;
+        if (ptr >= limit) { ptr -= consumed >> 3; consumed &= 7; c = ld_u64(ptr); return 0; }
+        if (ptr == start) return consumed < 64 ? 1u : 2u;
+        uint32_t nb = consumed >> 3, res = 0;
+        if (ptr - nb < start) { nb = (uint32_t)(ptr - start); res = 1; }
+        ptr -= nb; consumed -= nb * 8; c = ld_u64(ptr);
+        return res;
+    }
+};
+
+// One table of a block, built by one lane: from the block's own description at payload offset `off` (advanced past
+// it), from the dictionary, or from the earlier block that defined it.  false on an invalid description.
+template <typename NormPtr, typename NextPtr>
+DEVI bool serial_seq_table(const BatchParams& p, const DevBlock& blk, int t, uint32_t* cells, NormPtr norm, NextPtr symNext, uint32_t& off, uint32_t& log)
+{
+    uint32_t const type = t == T_LL ? blk.llType : t == T_OF ? blk.ofType : blk.mlType;
+    int32_t const srcB = t == T_LL ? blk.llSrc : t == T_OF ? blk.ofSrc : blk.mlSrc;
+    const uint8_t* const payload = p.src + blk.srcOff;
+    if (type != SET_REPEAT) {
+        if (off > blk.cSize) return false;
+        uint32_t const h = dev_build_from_desc(t, type, payload + off, blk.cSize - off, cells, norm, symNext, log);
+        if (h == kFail) return false;
+        off += h;
+        return true;
+    }
+    if (srcB == SRC_DICT) {
+        log = t == T_LL ? p.dict->llLog : t == T_OF ? p.dict->ofLog : p.dict->mlLog;
+        const uint32_t* const dc = t == T_LL ? p.dict->ll : t == T_OF ? p.dict->of : p.dict->ml;
+        for (uint32_t u = 0; u < (1u << log); u++) cells[u] = dc[u];
+        return true;
+    }
+    if (srcB == SRC_NONE) return false;
+    DevBlock const sb = p.blocks[srcB];
+    const uint8_t* const sp = p.src + sb.srcOff;
+    uint32_t o = sb.seqHdrOff;
+    for (int u = 0; u < t; u++) {      // (T_LL, T_OF, T_ML are the order of the descriptions)
+        uint32_t const sz = dev_desc_size(u, u == T_LL ? sb.llType : sb.ofType, sp, o, sb.cSize, norm);
+        if (sz == kFail) return false;
+        o += sz;
+    }
+    if (o > sb.cSize) return false;
+    uint32_t const stype = t == T_LL ? sb.llType : t == T_OF ? sb.ofType : sb.mlType;
+    return dev_build_from_desc(t, stype, sp + o, sb.cSize - o, cells, norm, symNext, log) != kFail;
+}
+
+// Blocks listed by k_sequences: decoded again from the first sequence by one lane, exactly as
+// ZSTD_decompressSequences_body reads them (zstd_decompress_block.pas:1232-1320, ZSTD_decodeSequence :1083-1230), the
+// records of the fast path overwritten.  Input that takes this path is damaged; its cost does not matter.
+__global__ __launch_bounds__(64) void k_sequences_dry(BatchParams p)
+{
+    __shared__ uint32_t tLL[512], tML[512], tOF[256];
+    __shared__ int16_t norm[64];
+    __shared__ uint16_t symNext[64];
+    if (threadIdx.x != 0) return;
+    uint32_t const count = p.dryList[0];
+    for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
+        uint32_t const b = p.dryList[1 + i];
+        DevBlock const blk = p.blocks[b];
+        DevBlockState* const st = p.state + b;
+        uint4* const out = (uint4*)p.seqBuf + blk.seqBufOff;
+        uint32_t off = blk.seqHdrOff, logLL = 0, logOF = 0, logML = 0;
+        bool ok = serial_seq_table(p, blk, T_LL, tLL, norm, symNext, off, logLL) && serial_seq_table(p, blk, T_OF, tOF, norm, symNext, off, logOF) &&
+                  serial_seq_table(p, blk, T_ML, tML, norm, symNext, off, logML) && off < blk.cSize;
+        DStreamEmu bs;
+        ok = ok && bs.init(p.src + blk.srcOff + off, blk.cSize - off);
+        if (!ok) {      // (not reached: the fast path built the same tables and opened the same stream)
+            st->seqErr = E_corruption; st->seqValid = 0; st->tailErr = 0; st->regen = blk.litSize;
+            st->repOut[0] = kSlot0; st->repOut[1] = kSlot1; st->repOut[2] = kSlot2;
+            out[0] = make_uint4(0, 0, 0, 0);
+            continue;
+        }
+        // ZSTD_initFseState x3: LL, OF, ML (:1266-1268)
+        uint32_t sLL = bs.read(logLL); bs.reload();
+        uint32_t sOF = bs.read(logOF); bs.reload();
+        uint32_t sML = bs.read(logML); bs.reload();
+        Rep3 rep = {kSlot0, kSlot1, kSlot2};
+        uint32_t outPos = 0, litPos = 0;
+        for (uint32_t n = 0; n < blk.nbSeq; n++) {
+            uint32_t const cLL = tLL[sLL], cML = tML[sML], cOF = tOF[sOF];
+            uint32_t const ofBits = cell_addBits(T_OF, cOF), mlBits = cell_addBits(T_ML, cML), llBits = cell_addBits(T_LL, cLL);
+            uint32_t const llCode = cell_llCode(cLL), mlCode = cell_mlCode(cML);
+            uint32_t ta;
+            bool isReal = ofBits > 1;
+            uint32_t idx = 0;
+            if (isReal) {
+                uint32_t const real = ((1u << ofBits) - 3u) + bs.readFast(ofBits);
+                ta = real > 0x7FFFFFFFu ? 0x7FFFFFFFu : real;
+            } else {
+                idx = (ofBits ? 1u + bs.readFast(1) : 0u) + (llCode == 0 ? 1u : 0u);
+                ta = idx == 0 ? kSlot0 : idx == 1 ? kSlot1 : idx == 2 ? kSlot2 : (kSlot0 | 1u);
+            }
+            Rep3 nx;
+            nx.a = rep_subst(ta, rep.a, rep.b, rep.c);
+            nx.b = (isReal || idx >= 1) ? rep.a : rep.b;
+            nx.c = (isReal || idx >= 2) ? rep.b : rep.c;
+            rep = nx;
+            uint32_t ml = c_ML_base[mlCode < 53 ? mlCode : 0];
+            if (mlBits) ml += bs.readFast(mlBits);
+            if (ofBits + mlBits + llBits >= 31) bs.reload();       // :1171-1174
+            uint32_t ll = c_LL_base[llCode < 36 ? llCode : 0];
+            if (llBits) ll += bs.readFast(llBits);
+            // state update: LL, ML, OF (:1220-1225)
+            sLL = (cLL & 0x1FFu) + bs.read(cell_nbBits(cLL));
+            sML = (cML & 0x1FFu) + bs.read(cell_nbBits(cML));
+            sOF = (cOF & 0x1FFu) + bs.read(cell_nbBits(cOF));
+            bs.reload();
+            out[n] = make_uint4(rep.a, outPos, litPos, ll);
+            uint64_t const no = (uint64_t)outPos + ll + ml, nl = (uint64_t)litPos + ll;
+            outPos = no > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)no;
+            litPos = nl > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)nl;
+        }
+        out[blk.nbSeq] = make_uint4(0, outPos, litPos, 0);
+        st->seqErr = 0;
+        st->seqValid = blk.nbSeq;
+        st->tailErr = bs.reload() < 2 ? (uint32_t)E_corruption : 0u;       // (:1301)
+        st->regen = (uint64_t)outPos + (litPos <= blk.litSize ? blk.litSize - litPos : 0);
+        st->repOut[0] = rep.a; st->repOut[1] = rep.b; st->repOut[2] = rep.c;
     }
 }
 
@@ -2716,6 +2936,12 @@ void launch_sequences(const BatchParams& p, void* stream)
 {
     if (!p.nSeqJobs) return;
     hipLaunchKernelGGL(k_sequences, dim3((p.nSeqJobs + kSeqJobs - 1) / kSeqJobs), dim3(kSeqThreads), 0, (hipStream_t)stream, p);
+}
+void launch_sequences_dry(const BatchParams& p, void* stream)
+{
+    if (!p.nSeqJobs) return;
+    uint32_t const grid = p.nSeqJobs < 128 ? p.nSeqJobs : 128;
+    hipLaunchKernelGGL(k_sequences_dry, dim3(grid), dim3(64), 0, (hipStream_t)stream, p);
 }
 void launch_layout(const BatchParams& p, void* stream)
 {

@@ -37,7 +37,8 @@ constexpr size_t oState = oBlocks + up256(kMaxBlocks * sizeof(DevBlock));
 constexpr size_t oFlags = oState + up256(kMaxBlocks * sizeof(DevBlockState));
 constexpr size_t oLitJobs = oFlags + up256(kMaxBlocks);
 constexpr size_t oSeqJobs = oLitJobs + up256(kMaxBlocks * sizeof(uint32_t));
-constexpr size_t oPackTab = oSeqJobs + up256(kMaxBlocks * sizeof(uint32_t));
+constexpr size_t oDryList = oSeqJobs + up256(kMaxBlocks * sizeof(uint32_t));
+constexpr size_t oPackTab = oDryList + up256((kMaxBlocks + 1) * sizeof(uint32_t));
 constexpr size_t oLitBuf = oPackTab + up256(((size_t)kMaxBlocks * 33 + 1) * sizeof(uint4));
 constexpr size_t oLitTmp = oLitBuf + up256(kCapLit);
 constexpr size_t oSeqBuf = oLitTmp + up256(kCapTmp);
@@ -114,7 +115,8 @@ extern "C" size_t zstdgpu_decode_frames_noalloc(zstdgpu_ctx* ctx, const void* de
     launch_scan_frames((const uint8_t*)devSrc, srcBytes, (const FrameIn*)devFrames, nFrames, batchDictID, opts, frames, slots, totals, s, caps);
     if (hipMemsetAsync(blocks, 0, (size_t)kMaxBlocks * sizeof(DevBlock), s) != hipSuccess ||
         hipMemsetAsync(flags, 0, kMaxBlocks, s) != hipSuccess ||
-        hipMemsetAsync(state, 0, (size_t)kMaxBlocks * sizeof(DevBlockState), s) != hipSuccess) return mkerr(E_generic);
+        hipMemsetAsync(state, 0, (size_t)kMaxBlocks * sizeof(DevBlockState), s) != hipSuccess ||
+        hipMemsetAsync(ptr + oDryList, 0, sizeof(uint32_t), s) != hipSuccess) return mkerr(E_generic);
     launch_fill_blocks((const uint8_t*)devSrc, srcBytes, (const FrameIn*)devFrames, nFrames, batchDictID, opts, (ddict && ddict->hasEntropy) ? 1u : 0u,
                        frames, blocks, flags, kMaxBlocks, litJobs, seqJobs, totals, s, caps);
 
@@ -123,7 +125,7 @@ extern "C" size_t zstdgpu_decode_frames_noalloc(zstdgpu_ctx* ctx, const void* de
     p.src = (const uint8_t*)devSrc; p.dst = (uint8_t*)devDst;
     p.blocks = blocks; p.state = state; p.frames = frames; p.status = (DevFrameStatus*)devStatus;
     p.litBuf = ptr + oLitBuf; p.litTmp = ptr + oLitTmp; p.packTab = (uint4*)(ptr + oPackTab); p.seqBuf = (uint32_t*)(ptr + oSeqBuf);
-    p.litJobs = litJobs; p.seqJobs = seqJobs;
+    p.litJobs = litJobs; p.seqJobs = seqJobs; p.dryList = (uint32_t*)(ptr + oDryList);
     p.nLitJobs = kMaxBlocks; p.nSeqJobs = kMaxBlocks; p.nFrames = nFrames; p.nBlocks = kMaxBlocks;
     p.devTotals = totals;
     if (ddict) {
@@ -134,6 +136,7 @@ extern "C" size_t zstdgpu_decode_frames_noalloc(zstdgpu_ctx* ctx, const void* de
     launch_literals(p, s);
     launch_pack_literals(p, s);
     launch_sequences(p, s);
+    launch_sequences_dry(p, s);
     launch_layout(p, s);
     launch_execute(p, s);
     launch_checksum(p, s);

@@ -168,7 +168,7 @@ struct zstdgpu_batch {
     uint32_t nFrames = 0, nBlocks = 0, nLitJobs = 0, nSeqJobs = 0;
     bool mirrored = true;
     DevBlock* dBlocks = nullptr; DevBlockState* dState = nullptr; DevFrame* dFrames = nullptr; DevFrameStatus* dStatus = nullptr;
-    uint8_t* dLitBuf = nullptr; uint8_t* dLitTmp = nullptr; uint4* dPackTab = nullptr; uint32_t* dSeqBuf = nullptr; uint32_t *dLitJobs = nullptr, *dSeqJobs = nullptr;
+    uint8_t* dLitBuf = nullptr; uint8_t* dLitTmp = nullptr; uint4* dPackTab = nullptr; uint32_t* dSeqBuf = nullptr; uint32_t *dLitJobs = nullptr, *dSeqJobs = nullptr, *dDryList = nullptr;
     size_t litBufBytes = 0, litTmpBytes = 0, seqBufBytes = 0;      // real sizes of the two big buffers (they return to the context's spare list)
     uint64_t litBytes = 0, nSeqTotal = 0, srcBytes = 0, scratchBytes = 0;
     bool profiling = false;
@@ -288,7 +288,7 @@ void free_batch_device(zstdgpu_batch* b)
     if (b->launched) { hipStreamSynchronize(b->lastStream); if (b->side) hipStreamSynchronize(b->side); }
     hipFree(b->dBlocks); hipFree(b->dState); hipFree(b->dFrames); hipFree(b->dStatus);
     bfree(b->ctx, b->dLitBuf, b->litBufBytes); bfree(b->ctx, b->dLitTmp, b->litTmpBytes); bfree(b->ctx, b->dSeqBuf, b->seqBufBytes);
-    hipFree(b->dLitJobs); hipFree(b->dSeqJobs); hipFree(b->dPackTab);
+    hipFree(b->dLitJobs); hipFree(b->dSeqJobs); hipFree(b->dPackTab); hipFree(b->dDryList);
     if (b->evReady) for (auto& e : b->ev) hipEventDestroy(e);
     if (b->side) hipStreamDestroy(b->side);
     if (b->evFork) hipEventDestroy(b->evFork);
@@ -656,7 +656,8 @@ extern "C" zstdgpu_batch* zstdgpu_batch_create(zstdgpu_ctx* ctx, const void* hos
     bool ok = dalloc(B->dBlocks, nBlocks, B->scratchBytes) && dalloc(B->dState, nBlocks, B->scratchBytes) &&
               dalloc(B->dFrames, nFrames, B->scratchBytes) && dalloc(B->dStatus, nFrames, B->scratchBytes) &&
               balloc(ctx, B->dLitBuf, B->litBytes, B->litBufBytes, B->scratchBytes) && balloc(ctx, B->dLitTmp, tmpOff + 64, B->litTmpBytes, B->scratchBytes) && balloc(ctx, B->dSeqBuf, seqOff * 4 + 4, B->seqBufBytes, B->scratchBytes) &&
-              dalloc(B->dLitJobs, B->hLitJobs.size(), B->scratchBytes) && dalloc(B->dPackTab, B->hLitJobs.size() * 33 + 1, B->scratchBytes) && dalloc(B->dSeqJobs, B->hSeqJobs.size(), B->scratchBytes);
+              dalloc(B->dLitJobs, B->hLitJobs.size(), B->scratchBytes) && dalloc(B->dPackTab, B->hLitJobs.size() * 33 + 1, B->scratchBytes) && dalloc(B->dSeqJobs, B->hSeqJobs.size(), B->scratchBytes) &&
+              dalloc(B->dDryList, B->hSeqJobs.size() + 1, B->scratchBytes);
     auto up = [&](void* d, const void* h, size_t n) { return n == 0 || hipMemcpy(d, h, n, hipMemcpyHostToDevice) == hipSuccess; };
     ok = ok && up(B->dBlocks, B->hBlocks.data(), nBlocks * sizeof(DevBlock)) && up(B->dFrames, B->hFrames.data(), nFrames * sizeof(DevFrame)) &&
          up(B->dLitJobs, B->hLitJobs.data(), B->hLitJobs.size() * 4) && up(B->dSeqJobs, B->hSeqJobs.data(), B->hSeqJobs.size() * 4);
@@ -719,7 +720,8 @@ extern "C" zstdgpu_batch* zstdgpu_batch_create_on_device(zstdgpu_ctx* ctx, const
         size_t const nLit = (size_t)totals[4], nSeq = (size_t)totals[5];
         B->litBytes = litOff + 64; B->nSeqTotal = seqOff;
         ok = balloc(ctx, B->dLitBuf, B->litBytes, B->litBufBytes, B->scratchBytes) && balloc(ctx, B->dLitTmp, tmpOff + 64, B->litTmpBytes, B->scratchBytes) &&
-             balloc(ctx, B->dSeqBuf, seqOff * 4 + 4, B->seqBufBytes, B->scratchBytes) && dalloc(B->dPackTab, nLit * 33 + 1, B->scratchBytes);
+             balloc(ctx, B->dSeqBuf, seqOff * 4 + 4, B->seqBufBytes, B->scratchBytes) && dalloc(B->dPackTab, nLit * 33 + 1, B->scratchBytes) &&
+             dalloc(B->dDryList, nSeq + 1, B->scratchBytes);
         B->nFrames = nFrames; B->nBlocks = nBlocks; B->nLitJobs = (uint32_t)nLit; B->nSeqJobs = (uint32_t)nSeq;
         B->srcBytes = totals[6];
         B->mirrored = false;
@@ -775,7 +777,7 @@ extern "C" size_t zstdgpu_batch_decode(zstdgpu_batch* B, const void* devSrc, voi
     BatchParams p{};
     p.src = (const uint8_t*)devSrc; p.dst = (uint8_t*)devDst;
     p.blocks = B->dBlocks; p.state = B->dState; p.frames = B->dFrames; p.status = B->dStatus;
-    p.litBuf = B->dLitBuf; p.litTmp = B->dLitTmp; p.packTab = B->dPackTab; p.seqBuf = B->dSeqBuf; p.litJobs = B->dLitJobs; p.seqJobs = B->dSeqJobs;
+    p.litBuf = B->dLitBuf; p.litTmp = B->dLitTmp; p.packTab = B->dPackTab; p.seqBuf = B->dSeqBuf; p.litJobs = B->dLitJobs; p.seqJobs = B->dSeqJobs; p.dryList = B->dDryList;
     p.nLitJobs = B->nLitJobs; p.nSeqJobs = B->nSeqJobs;
     p.nFrames = B->nFrames; p.nBlocks = B->nBlocks;
     if (B->ddict) {
@@ -792,6 +794,7 @@ extern "C" size_t zstdgpu_batch_decode(zstdgpu_batch* B, const void* devSrc, voi
     bool const prof = B->profiling && B->evReady;
     if (prof) hipEventRecord(B->ev[0], s);
     if (p.nBlocks) hipMemsetAsync(B->dState, 0, (size_t)p.nBlocks * sizeof(DevBlockState), s);
+    hipMemsetAsync(B->dDryList, 0, sizeof(uint32_t), s);
     launch_literals(p, s);
     if (prof) hipEventRecord(B->ev[1], s);
     // the pack of split-decoded literals needs nothing from the sequence stage and leaves it most of the chip: side stream
@@ -800,6 +803,7 @@ extern "C" size_t zstdgpu_batch_decode(zstdgpu_batch* B, const void* devSrc, voi
     launch_pack_literals(p, B->side);
     hipEventRecord(B->evJoin, B->side);
     launch_sequences(p, s);
+    launch_sequences_dry(p, s);
     if (prof) hipEventRecord(B->ev[2], s);
     launch_layout(p, s);
     if (prof) hipEventRecord(B->ev[3], s);

@@ -107,6 +107,7 @@ struct BatchParams {
     uint32_t* seqBuf;            // triples (litLength, matchLength, offset)
     const uint32_t* litJobs;     // block indices with Huffman-coded literals
     const uint32_t* seqJobs;     // block indices with nbSeq > 0
+    uint32_t* dryList;           // [0] count (cleared before every launch), then the blocks whose sequence stream ran dry early
     const DevDict* dict;         // may be null
     const uint8_t* dictContent;  // device pointer to dictionary content
     uint32_t dictContentSize;
@@ -140,6 +141,7 @@ void launch_fill_blocks(const uint8_t* src, uint64_t srcBytes, const FrameIn* in
 void launch_literals(const BatchParams& p, void* stream);
 void launch_pack_literals(const BatchParams& p, void* stream);
 void launch_sequences(const BatchParams& p, void* stream);
+void launch_sequences_dry(const BatchParams& p, void* stream);
 void launch_layout(const BatchParams& p, void* stream);
 void launch_execute(const BatchParams& p, void* stream);
 void launch_checksum(const BatchParams& p, void* stream);
