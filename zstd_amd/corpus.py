@@ -76,6 +76,8 @@ class SystemZstd:
         L.ZSTD_compress2.restype = ctypes.c_size_t
         L.ZSTD_decompress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t]
         L.ZSTD_decompress.restype = ctypes.c_size_t
+        L.ZSTD_decompressDCtx.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t]
+        L.ZSTD_decompressDCtx.restype = ctypes.c_size_t
         L.ZSTD_createDCtx.restype = ctypes.c_void_p
         L.ZSTD_freeDCtx.argtypes = [ctypes.c_void_p]
         L.ZSTD_decompress_usingDict.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p,
