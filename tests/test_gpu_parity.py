@@ -361,6 +361,39 @@ def test_device_walk_equals_host_walk_on_every_fixture(dctx):
     assert [int(x) for x in st["errorCode"][len(entries):]] == [72, 72, 72, 72]
 
 
+@pytest.mark.parametrize("kernel", ["one", "eight"])
+def test_every_fixture_through_each_execute_kernel(dctx, kernel, monkeypatch):
+    """The two execute kernels (one wave per frame, eight waves per frame) are chosen by the shape of the batch; here each
+    decodes every fixture, valid or damaged, with and without the dictionary: verdicts and bytes as the oracle's."""
+    import torch
+    monkeypatch.setenv("ZSTDGPU_EXECUTE", kernel)
+    for dict_name in (None, "dict16k"):
+        entries = [e for e in FRAMES if e.get("dict") == dict_name and e["capacity"] <= (1 << 20) and e["csize"] > 0
+                   and not e["name"].startswith(("concat", "skippable", "rec_nodict"))]
+        if not entries:
+            continue
+        dictionary = read_dict(dict_name) if dict_name else None
+        ddict = api.DDict(dctx, dictionary) if dictionary else None
+        frames = [read_frame(e) for e in entries]
+        src, fin, dst_bytes = api.pack_frames(frames, [e["capacity"] for e in entries])
+        d_src = torch.from_numpy(src).cuda()
+        d_dst = torch.zeros(max(dst_bytes, 1), dtype=torch.uint8, device="cuda")
+        b = api.Batch(dctx, src, fin, ddict)
+        b.decode(d_src.data_ptr(), d_dst.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        st = b.status().copy()
+        out = d_dst.cpu().numpy()
+        b.close()
+        for i, e in enumerate(entries):
+            want, werr = oracle.decompress(frames[i], e["capacity"], dictionary)
+            assert int(st[i]["errorCode"]) == werr, (kernel, e["name"])
+            if not werr:
+                o = int(fin[i]["dstOff"])
+                assert int(st[i]["regenSize"]) == len(want), (kernel, e["name"])
+                assert out[o:o + len(want)].tobytes() == want, (kernel, e["name"])
+        if ddict:
+            ddict.close()
+
+
 def test_device_walk_with_dictionary(dctx):
     d = read_dict("dict16k")
     dd = api.DDict(dctx, d)

@@ -38,6 +38,8 @@ def _noalloc(dctx, src, fin, dst_bytes, ddict=None):
     d_fin = torch.from_numpy(fin.view(np.uint8).copy()).cuda()
     d_dst = torch.full((dst_bytes,), 0x5A, dtype=torch.uint8, device="cuda")
     d_st = torch.full((max(len(fin), 1) * api.FRAME_STATUS_DTYPE.itemsize,), 0xEE, dtype=torch.uint8, device="cuda")
+    import gc
+    gc.collect()        # (what the collector frees during the call would show as a change too)
     torch.cuda.synchronize()
     before = torch.cuda.memory_allocated()
     api.decode_frames_noalloc(dctx, d_src.data_ptr(), src.nbytes, d_fin.data_ptr(), len(fin), d_dst.data_ptr(), d_st.data_ptr(),

@@ -15,6 +15,8 @@
 // All arithmetic is integer; wave = 64 lanes; every workgroup is a single wave, so lanes of a
 // workgroup run in lockstep and exchange data through LDS with a fence only.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
+#include <cstring>
 #include "zstdgpu_internal.h"
 
 namespace zg {
@@ -2470,6 +2472,18 @@ DEVI uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane(
 DEVI uint64_t uni(uint64_t v) { return ((uint64_t)uni((uint32_t)(v >> 32)) << 32) | uni((uint32_t)v); }
 DEVI uint32_t lane_value(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
 
+// Whether a frame is decoded by k_execute_wf (eight waves) or by k_execute (one): by eight waves when its blocks carry
+// enough sequences on average for the waves to have batches to share.  Same answer in both kernels.  p.execMode
+// forces one or the other (set by launch_execute).
+DEVI bool frame_uses_wf(const BatchParams& p, const DevFrame& f)
+{
+    if (p.execMode) return p.execMode == 2;
+    uint64_t seqs = 0;
+    uint32_t const nb = f.nBlocks < 64 ? f.nBlocks : 64;       // (the first blocks tell)
+    for (uint32_t b = f.firstBlock; b < f.firstBlock + nb; b++) seqs += p.blocks[b].nbSeq;
+    return nb != 0 && seqs >= 1024ull * nb;
+}
+
 constexpr uint32_t kOutStage = 4096;     // output bytes of one batch assembled in LDS
 constexpr uint32_t kOutHist = 7168;      // the output stage: a batch and the output of the batches before it
 constexpr uint32_t kOutKeep = kOutHist - kOutStage;     // history kept when the stage is full (its tail moves to the front)
@@ -2495,6 +2509,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
     DevFrame const f = p.frames[fi];
     DevFrameStatus* const fs = p.status + fi;
     if (fs->errorCode) return;   // host error or unusable dictionary (set by k_layout)
+    if (frame_uses_wf(p, f)) return;        // k_execute_wf's
     uint8_t* const fdst = p.dst + f.dstOff;
     uint64_t const cap = f.dstCapacity;
     uint32_t const dictN = f.useDict ? p.dictContentSize : 0;
@@ -2801,6 +2816,604 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
     if (lane == 0) { fs->regenSize = produced; fs->errorCode = ferr; }
 }
 
+// ---------------------------------------------------------------- stage 3b: execute, eight waves per frame
+// The sequences of a block must take effect in order, but most of the work of a batch of 64 does not depend on the
+// batches just before it; k_execute above leaves its one wave idle through every wait.  Here the waves of a workgroup
+// take the batches of a block in turn (wave w: batches w, w + 8, ...) and assemble them in ONE ring of the block's
+// recent output, in LDS, shared by the workgroup.  Per batch:
+//   early (nothing waited for)  records (requested one batch earlier), plan; literal bytes and the match sources that
+//                       lie far back come from memory into the ring; matches whose source lies in completed batches are
+//                       copied ring to ring.  For what has to wait, the moves are worked out byte by byte and kept in
+//                       registers: the bytes of the matches whose source is still being assembled are dealt out four to
+//                       a lane; each match that depends on the batch itself (or repeats a pattern) gets a round of one
+//                       byte per lane.
+//   late (in turn)      once every earlier batch is complete -- they complete in order -- the dealt bytes move in ONE
+//                       round trip to LDS, then the dependent matches one round each, in sequence order.
+//   after               the batch is marked complete; its bytes go from the ring to memory with whole-wave stores, and
+//                       are announced as flushed when the wave comes round to its next batch (the stores have landed
+//                       by then: they precede the record loads the wave has to wait for anyway).
+// What the waves wait for one another on is the late step alone.  Control words in LDS (polled): {batches complete,
+// output position complete, ring floor, error} and {batches flushed, output position flushed}.
+// A batch with too much output for its share of the ring goes from memory to memory as in k_execute, after everything
+// before it has been flushed; it raises the ring floor past itself (its bytes are not in the ring).  A batch with a
+// late source outside the ring's reach does its late part the slow way: match after match in sequence order, from
+// memory where it must.
+constexpr int kWf = 8;
+constexpr uint32_t kWfMaxFrames = 1024;   // batches of more frames than this are decoded by k_execute alone
+constexpr uint32_t kWfRing = 32768, kWfMask = kWfRing - 1;
+constexpr uint32_t kWfHist = 16384;       // a match source at most this far before its batch is read from the ring
+constexpr uint32_t kWfStage = 3072;       // most output bytes of a batch assembled in the ring
+constexpr uint32_t kWfLitStage = 2048;    // most literal bytes of such a batch
+enum { WF_DONE = 0, WF_DONEPOS, WF_FLOOR, WF_ERR, WF_FLUSHED, WF_FLUSHEDPOS };
+constexpr uint32_t kWfAbort = 0x7FFFFFFFu;
+#ifndef ZG_WF_NAP
+#define ZG_WF_NAP 1
+#endif
+constexpr int kWfNap = ZG_WF_NAP;         // s_sleep between polls of the control words: a polling wave leaves the LDS and its SIMD to the others
+constexpr uint32_t kWfTabWords = 64;      // head bytes[256] of the list of late bytes
+enum { WFC_NONE = 0, WFC_EARLY, WFC_LATE_RING, WFC_DEPENDENT, WFC_LATE_MEMORY };
+
+DEVI void wf_barrier()
+{
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// Two runs of 0..32 bytes into the ring, at block-relative positions dA and dB: run A from a linear LDS buffer, run B
+// from one or (bRing) from the ring at position sB.  A run that crosses the ring's end goes byte by byte.
+DEVI void wf_copy_runs(uint8_t* ring, uint32_t dA, const uint8_t* srcA, uint32_t lenA, uint32_t dB, const uint8_t* srcB, bool bRing, uint32_t sB, uint32_t lenB)
+{
+    uint32_t const a = dA & kWfMask, b = dB & kWfMask, sb = sB & kWfMask;
+    bool const wrapA = a + lenA > kWfRing;
+    bool const wrapB = (b + lenB > kWfRing) | (bRing & (sb + lenB > kWfRing));
+    lds_copy_runs(ring + a, srcA, wrapA ? 0u : lenA, ring + b, bRing ? ring + sb : srcB, wrapB ? 0u : lenB);
+    if (wrapA) for (uint32_t j = 0; j < lenA; j++) ring[(dA + j) & kWfMask] = srcA[j];
+    if (wrapB) for (uint32_t j = 0; j < lenB; j++) ring[(dB + j) & kWfMask] = bRing ? ring[(sB + j) & kWfMask] : srcB[j];
+}
+
+// inclusive prefix maximum over the 64 lanes of a wave (all lanes active)
+DEVI uint32_t wave_incl_max(uint32_t v)
+{
+    v = max(v, dpp_or0<0x111, 0xF>(v)); v = max(v, dpp_or0<0x112, 0xF>(v)); v = max(v, dpp_or0<0x114, 0xF>(v)); v = max(v, dpp_or0<0x118, 0xF>(v));
+    v = max(v, dpp_or0<0x142, 0xA>(v));
+    v = max(v, dpp_or0<0x143, 0xC>(v));
+    return v;
+}
+// value of the next lower lane (0 in lane 0)
+DEVI uint32_t wave_prev0(uint32_t x) { return dpp_or0<0x138, 0xF>(x); }
+
+// The late step of a batch.  First, four single bytes per lane ring to ring, every load before the first store and no
+// branch -- one LDS round trip for the whole wave; no source is another lane's destination.  Then the dependent matches
+// in sequence order, each one byte per lane (source | destination << 16).  A lane with nothing to move moves its own
+// spare byte behind the ring onto itself.  Offsets are worked out by the caller ahead of the wait for the batch's turn.
+constexpr int kWfDeps = 6;
+struct WfLateStep {
+    uint32_t d[4], s[4];          // ring offsets
+    uint32_t dep[kWfDeps];
+    DEVI void pin()
+    {
+        // (worked out here and now, not after the wait that follows)
+        asm volatile("" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]));
+        asm volatile("" : "+v"(dep[0]), "+v"(dep[1]), "+v"(dep[2]), "+v"(dep[3]), "+v"(dep[4]), "+v"(dep[5]));
+    }
+    DEVI void run_list(uint8_t* ring) const
+    {
+        uint8_t const v0 = ring[s[0]], v1 = ring[s[1]], v2 = ring[s[2]], v3 = ring[s[3]];
+        ring[d[0]] = v0; ring[d[1]] = v1; ring[d[2]] = v2; ring[d[3]] = v3;
+    }
+    DEVI void run_deps(uint8_t* ring, uint32_t n) const
+    {
+#pragma unroll
+        for (int k = 0; k < kWfDeps; k++)
+            if ((uint32_t)k < n) { uint8_t const v = ring[dep[k] & 0xFFFF]; ring[dep[k] >> 16] = v; }     // (LDS operations of a wave execute in order)
+    }
+};
+
+// Polls LDS control words until `cond`; what follows is not moved above it.  The wait is bounded (far beyond what a
+// block can take): should the protocol ever stall, the frame ends with an error instead of a wave that never finishes.
+#define WF_SPIN(cond)                                                                                   \
+    do {                                                                                                \
+        uint32_t spins_ = 0;                                                                            \
+        while (!(cond)) {                                                                               \
+            __builtin_amdgcn_s_sleep(kWfNap);                                                           \
+            if (++spins_ > (1u << 22)) { ctl[WF_ERR] = E_generic; ctl[WF_DONE] = kWfAbort; stalled = true; break; } \
+        }                                                                                               \
+        asm volatile("" ::: "memory");                                                                  \
+    } while (0)
+
+__global__ __launch_bounds__(64 * kWf) __attribute__((amdgpu_waves_per_eu(4))) void k_execute_wf(BatchParams p)
+{
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+    __shared__ __attribute__((aligned(16))) uint8_t ring[kWfRing + 64 * kWf];        // + a spare byte per lane
+    __shared__ __attribute__((aligned(16))) uint8_t litStageAll[kWf][kWfLitStage];
+    __shared__ __attribute__((aligned(16))) uint8_t matStageAll[kWf][64 * 32];
+    __shared__ __attribute__((aligned(16))) uint32_t tabAll[kWf][kWfTabWords];
+    __shared__ __attribute__((aligned(16))) uint32_t ctlMem[8];
+    // (typed as LDS on purpose: a volatile access through a generic pointer is a flat memory operation, many times slower)
+    typedef __attribute__((address_space(3))) volatile uint32_t LdsWord;
+    typedef __attribute__((address_space(3))) volatile v2u LdsPair;
+    typedef __attribute__((address_space(3))) volatile v4u LdsQuad;
+    LdsWord* const ctl = (LdsWord*)ctlMem;
+    uint32_t const tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    uint8_t* const litStage = litStageAll[wave];
+    uint8_t* const matStage = matStageAll[wave];
+    uint32_t* const tHeads = tabAll[wave];
+    // sequence table of a batch that goes from memory to memory (it uses neither stage)
+    uint32_t* const sStart = (uint32_t*)matStage;
+    uint32_t* const sLL = sStart + 65;
+    uint32_t* const sOff = sLL + 64;
+    uint32_t* const sLit = sOff + 64;
+    uint32_t* const sSlowEnd = sLit + 64;
+    uint32_t const fi = blockIdx.x;
+    DevFrame const f = p.frames[fi];
+    DevFrameStatus* const fs = p.status + fi;
+    if (fs->errorCode) return;
+    if (!frame_uses_wf(p, f)) return;
+    uint8_t* const fdst = p.dst + f.dstOff;
+    uint64_t const cap = f.dstCapacity;
+    uint32_t const dictN = f.useDict ? p.dictContentSize : 0;
+    const uint8_t* const dictEnd = p.dictContent + dictN;
+    uint32_t ferr = 0;
+    uint64_t produced = 0;
+
+    for (uint32_t b = f.firstBlock; b < f.firstBlock + f.nBlocks && !ferr; b++) {
+        const DevBlock* const bp = p.blocks + b;
+        const DevBlockState* const sp_ = p.state + b;
+        uint32_t const blockType = uni((uint32_t)bp->blockType), origSize = uni(bp->origSize);
+        uint64_t const blkSrcOff = uni(bp->srcOff);
+        uint32_t const hostLitErr = uni((uint32_t)bp->hostLitErr), hostSeqErr = uni((uint32_t)bp->hostSeqErr);
+        uint32_t const litType = uni((uint32_t)bp->litType), nbSeq = uni(bp->nbSeq);
+        uint64_t const bo = produced;
+        uint64_t const room = cap - bo;
+        if (blockType == BT_STOP) { ferr = hostLitErr; break; }
+        if (blockType == BT_RAW || blockType == BT_RLE) {
+            if (origSize > room) { ferr = E_dstSize_tooSmall; break; }
+            if (blockType == BT_RAW) { const uint8_t* const sp = p.src + blkSrcOff; for (uint64_t i = tid; i < origSize; i += 64 * kWf) fdst[bo + i] = sp[i]; }
+            else { uint8_t const v = p.src[blkSrcOff]; for (uint64_t i = tid; i < origSize; i += 64 * kWf) fdst[bo + i] = v; }
+            produced += origSize;
+            wf_barrier();       // in memory before a later block reads them
+            continue;
+        }
+        if (hostLitErr) { ferr = hostLitErr; break; }
+        bool const hufLits = litType >= SET_COMPRESSED;
+        uint32_t const litErr = uni(sp_->litErr), seqErr = uni(sp_->seqErr), tailErr = uni(sp_->tailErr);
+        if (hufLits && litErr) { ferr = litErr; break; }
+        if (hostSeqErr) { ferr = hostSeqErr; break; }
+        if (nbSeq && seqErr) { ferr = seqErr; break; }
+
+        const uint8_t* const litBase = hufLits ? p.litBuf + uni(bp->litBufOff) : p.src + blkSrcOff + uni((uint32_t)bp->litHdrSize);
+        bool const litRle = (litType == SET_RLE);
+        uint32_t const litSize = uni(bp->litSize);
+        uint32_t const rleFill = (litRle && litSize) ? 0x01010101u * uni((uint32_t)litBase[0]) : 0u;
+        uint32_t const nValid = nbSeq ? uni(sp_->seqValid) : 0;
+        const uint4* const recs = (const uint4*)p.seqBuf + uni(bp->seqBufOff);
+        uint32_t const rin0 = uni(sp_->repIn[0]), rin1 = uni(sp_->repIn[1]), rin2 = uni(sp_->repIn[2]);
+        uint32_t const nBatches = (nValid + 63) >> 6;
+        uint8_t* const bdst = fdst + bo;                  // the block's output
+
+        wf_barrier();           // every wave is through with the block before (its control words, its flushes)
+        if (tid < 8) ctlMem[tid] = 0;
+        wf_barrier();
+
+        // records of this wave's next batch, requested a batch ahead (past the last batch: nothing)
+        v4u rN = {0, 0, 0, 0};
+        v2u eN = {0, 0};
+        auto load_recs = [&](uint32_t bt2) {
+            if (bt2 < nBatches) {
+                uint32_t const s = bt2 << 6;
+                uint32_t const n2 = nValid - s < 64 ? nValid - s : 64;
+                rN = __builtin_nontemporal_load((const v4u*)(recs + s + (lane < n2 ? lane : n2)));
+                eN = __builtin_nontemporal_load((const v2u*)((const uint32_t*)(recs + s + n2) + 1));
+            }
+        };
+        load_recs(wave);
+        bool stalled = false;
+        bool flushPending = false;          // this wave's last batch is on its way to memory, not yet announced
+        uint32_t fpBt = 0, fpEnd = 0;
+        // announces the flush of the wave's previous batch: its stores have landed, and every earlier batch is announced
+        auto announce = [&]() {
+            if (flushPending) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                WF_SPIN(uni(ctl[WF_FLUSHED]) >= fpBt);
+                if (lane == 0) { v2u const w = {fpBt + 1, fpEnd}; *(LdsPair*)(ctlMem + WF_FLUSHED) = w; }
+                flushPending = false;
+            }
+        };
+        for (uint32_t bt = wave; bt < nBatches && !stalled; bt += kWf) {
+            uint32_t const s0 = bt << 6;
+            uint32_t const n = nValid - s0 < 64 ? nValid - s0 : 64;
+#ifdef ZG_STAMPS
+            uint64_t const y0 = __builtin_readcyclecounter();
+            uint64_t y1 = y0, y2 = y0, y3 = y0, y4 = y0, y5 = y0;
+            uint32_t nLate = 0, nSlow = 0, nFarLate = 0, nHops = 0, wentSlow = 0;
+            uint32_t const slowTotal = 0;
+            uint64_t z1 = y0, z2 = y0, z3 = y0, z4 = y0, z5 = y0, z6 = y0;
+#endif
+            announce();
+#ifdef ZG_STAMPS
+            z1 = __builtin_readcyclecounter();
+#endif
+            // ---- records and plan (see k_execute: the same per-sequence facts and checks)
+            v4u const r4 = rN;
+            v2u const e2v = eN;
+            bool const have = lane < n;
+            uint32_t const endY = uni(e2v.x), endZ = uni(e2v.y);
+            uint32_t const below = wave_next(r4.y);
+            uint32_t const nstart = lane == 63 ? endY : (have ? below : r4.y);
+            uint32_t const bstart = r4.y;
+            uint32_t const lstart = r4.z;
+            uint32_t const ll = have ? r4.w : 0;
+            uint32_t const offR = rep_subst(r4.x, rin0, rin1, rin2);
+            uint32_t const off = have ? offR : 1;
+            bool const e1 = nstart > room;
+            bool const e2 = (uint64_t)lstart + ll > litSize;
+            bool const e3 = (uint64_t)off > bo + bstart + ll + dictN;
+            uint32_t const code = !have ? 0u : e1 ? (uint32_t)E_dstSize_tooSmall : (e2 | e3) ? (uint32_t)E_corruption : 0u;
+            unsigned long long const badm = __ballot(code != 0);
+            uint32_t const perr = badm ? uni((uint32_t)__shfl(code, __builtin_ctzll(badm))) : 0u;
+            uint32_t const ml = nstart - bstart - ll;
+            uint32_t const base0 = lane_value(bstart, 0);
+            uint32_t const start = bstart - base0;
+            uint32_t const total = lane_value(nstart, 63) - base0;
+            uint32_t const lit0 = lane_value(lstart, 0);
+            uint32_t const sumLL = endZ - lit0;
+            if (perr) {
+                // the first bad sequence in order ends the block: wait for this batch's turn, then tell everybody
+                WF_SPIN(ctl[WF_DONE] >= bt);
+                if (ctl[WF_DONE] == bt) { ctl[WF_ERR] = perr; asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); ctl[WF_DONE] = kWfAbort; }
+                break;
+            }
+            int64_t const ms = (int64_t)(start + ll) - (int64_t)off;           // batch-relative source start
+            int64_t const sp = (int64_t)base0 + ms;                             // block-relative
+            int64_t const absS = (int64_t)bo + sp;                              // frame-relative (negative: dictionary)
+            bool const plain = have & (off >= ml) & (ms + (int64_t)ml <= 0) & ((absS >= 0) | (absS + (int64_t)ml <= 0));
+            int64_t const fetchEnd = absS + (ml > 16 ? 32 : 16);
+            bool const fetchable = plain & (absS >= 0 ? fetchEnd <= (int64_t)cap : fetchEnd <= 0);
+            bool const staged = (total <= kWfStage) & (sumLL <= kWfLitStage);
+            const uint8_t* const matSrc = absS >= 0 ? fdst + absS : dictEnd + absS;
+
+            if (!staged) {
+                // ---- memory to memory, once everything before the batch is in memory
+                WF_SPIN(ctl[WF_DONE] == kWfAbort || (ctl[WF_DONE] >= bt && ctl[WF_FLUSHED] >= bt));
+                if (ctl[WF_DONE] != bt) break;         // an earlier batch failed
+#ifdef ZG_STAMPS
+                y1 = __builtin_readcyclecounter();
+#endif
+                uint32_t const fastLenD = plain ? ml : 0, slowLen = (have && !plain) ? ml : 0;
+                uint32_t const slowEnd = wave_incl_scan(slowLen);
+                uint32_t const slowTotal = lane_value(slowEnd, 63);
+                lds_sync();
+                sStart[lane] = start; sLL[lane] = ll; sOff[lane] = off; sLit[lane] = lstart; sSlowEnd[lane] = slowEnd;
+                if (lane == 63) sStart[64] = total;
+                lds_sync();
+                exec_batch_direct(sStart, sLL, sOff, sLit, sSlowEnd, litBase, fdst, dictEnd, (int64_t)(bo + base0), litRle, bdst + base0 + start,
+                                  litRle ? litBase : litBase + lstart, matSrc, ll, fastLenD, slowTotal, bdst + base0, lane);
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                if (lane == 0) {
+                    ctl[WF_FLOOR] = base0 + total;          // nothing of this batch is in the ring
+                    v2u const w = {bt + 1, base0 + total};
+                    *(LdsPair*)(ctlMem + WF_FLUSHED) = w;
+                    *(LdsPair*)(ctlMem + WF_DONE) = w;
+                }
+#ifdef ZG_STAMPS
+                if (p.dbg && lane == 0) {
+                    unsigned long long* const g = (unsigned long long*)(p.dbg + 32 * (size_t)p.nBlocks + 32 * fi);
+                    atomicAdd(g + 10, 1ull); atomicAdd(g + 11, y1 - y0); atomicAdd(g + 12, __builtin_readcyclecounter() - y1);
+                }
+#endif
+                load_recs(bt + kWf);
+                continue;
+            }
+
+#ifdef ZG_STAMPS
+            z2 = __builtin_readcyclecounter();
+#endif
+            // ---- early part.  The ring must not be overwritten under a batch still being assembled (it may look kWfHist
+            // back) nor before its bytes have been flushed: both hold once this batch ends within ring - history of the
+            // completed and within a ring of the flushed output.
+            WF_SPIN(uni(ctl[WF_DONE]) == kWfAbort || (base0 + total <= uni(ctl[WF_DONEPOS]) + (kWfRing - kWfHist) && base0 + total <= uni(ctl[WF_FLUSHEDPOS]) + kWfRing));
+            v4u const c0 = *(LdsQuad*)ctlMem;
+            v2u const f0 = *(LdsPair*)(ctlMem + WF_FLUSHED);
+            if (uni(c0.x) == kWfAbort) break;
+            uint32_t const donePos0 = uni(c0.y), floor0 = uni(c0.z), flushedPos0 = uni(f0.y);
+            bool const nearS = plain & (sp >= (int64_t)floor0) & (sp + (int64_t)kWfHist >= (int64_t)base0);   // source in the ring's reach
+            bool const nearNow = nearS & (sp + (int64_t)ml <= (int64_t)donePos0);           // ... and complete already
+            bool const farS = fetchable & !nearS;
+            bool const farNow = farS & (sp + (int64_t)ml <= (int64_t)flushedPos0);          // in memory already
+            bool const slowS = have & !nearS & !farS & (ml != 0);
+            uint32_t const cls = (ml == 0 || !have) ? (uint32_t)WFC_NONE : (nearNow | farNow) ? (uint32_t)WFC_EARLY : nearS ? (uint32_t)WFC_LATE_RING
+                                 : farS ? (uint32_t)WFC_LATE_MEMORY : (uint32_t)WFC_DEPENDENT;
+            uint32_t const litFull = sumLL >> 4, litTail = sumLL & 15;
+            const uint8_t* const safe = (const uint8_t*)recs;
+            const uint8_t* const litG = litBase + lit0;
+            bool const farFetch = farNow & (ml <= 32);          // (longer ones are copied piece by piece further down)
+            uint4 litV, mv0, mv1;
+            __builtin_memcpy(&litV, (!litRle && lane < litFull) ? litG + 16 * lane : safe, 16);
+            uint8_t const litT = *((!litRle && lane < litTail) ? litG + 16 * litFull + lane : safe);
+            __builtin_memcpy(&mv0, farFetch ? matSrc : safe, 16);
+            __builtin_memcpy(&mv1, (farFetch && ml > 16) ? matSrc + 16 : safe, 16);
+
+            bool const lateRing = nearS & !nearNow & (ml <= 32);          // (longer ones go with the long dependent matches)
+#ifdef ZG_STAMPS
+            z3 = __builtin_readcyclecounter();
+#endif
+            // ---- while those are in flight: the dependent matches.  The late step copies them one after the other in sequence
+            // order, one byte per lane; which byte from where is worked out here (byte j of a match copies pattern byte
+            // j mod offset; the pattern is the `offset` bytes before the match).  A late match of more than 32 bytes goes the
+            // same way.  Up to kWfDeps matches of up to 64 bytes, their patterns within the ring's reach; a batch with more
+            // does its late part the slow way.
+            uint32_t const dLit = base0 + start, dMat = base0 + start + ll;          // block-relative destinations
+            bool const dep = slowS | (nearS & !nearNow & (ml > 32));
+            bool const depBad = dep & ((ml > 64) | (sp < (int64_t)floor0) | (sp + (int64_t)kWfHist < (int64_t)base0));
+            unsigned long long const deps = __ballot(dep);
+            uint32_t const nDeps = (uint32_t)__builtin_popcountll(deps);
+            bool slowWay = __any((cls == WFC_LATE_MEMORY) | depBad) != 0;
+#ifdef ZG_STAMPS
+            uint32_t why = (__any(cls == WFC_LATE_MEMORY) ? 2u : 0u) | (__any(depBad) ? 4u : 0u);
+#endif
+            unsigned long long depsRest = deps;         // the dependent matches past the first kWfDeps: copied by a loop
+            // the lowest ring position this lane's part of the late step reads (should the floor rise above it in the meantime,
+            // those bytes are in memory, not in the ring)
+            uint32_t const lowSrc = (lateRing | dep) ? (uint32_t)sp : 0xFFFFFFFFu;
+            uint32_t const spare = kWfRing + 64 * wave + lane;
+            WfLateStep late;
+            for (int k = 0; k < 4; k++) late.d[k] = late.s[k] = spare;
+            for (int k = 0; k < kWfDeps; k++) late.dep[k] = spare | (spare << 16);
+            if (!slowWay) {
+#pragma unroll
+                for (int k = 0; k < kWfDeps; k++) {
+                    if (depsRest) {
+                        int const w = __builtin_ctzll(depsRest);
+                        depsRest &= depsRest - 1;
+                        uint32_t const d0 = lane_value(dMat, w), o = lane_value(off, w), m = lane_value(ml, w);
+                        uint32_t r = lane;
+                        if (o < 64) {       // lane mod offset: the quotient by a reciprocal, off by one at most
+                            uint32_t const q = (uint32_t)((float)lane * __builtin_amdgcn_rcpf((float)o));
+                            r = lane - q * o;
+                            r = (int32_t)r < 0 ? r + o : r;
+                            r = r >= o ? r - o : r;
+                        }
+                        if (lane < m) late.dep[k] = ((d0 - o + r) & kWfMask) | (((d0 + lane) & kWfMask) << 16);
+                    }
+                }
+            }
+
+#ifdef ZG_STAMPS
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            z4 = __builtin_readcyclecounter();
+#endif
+            // ---- the bytes of the matches whose source is still being assembled, dealt out four to a lane (lane l: bytes
+            // 4l .. 4l+3 of their concatenation).  Each such match marks its first byte with its lane; a prefix maximum
+            // carries the marks forward.
+            bool lateRun = false;
+            {
+                uint32_t const lrLen = lateRing ? ml : 0;
+                uint32_t const lrEnd = wave_incl_scan(lrLen);
+                // (the list holds 256 bytes; the matches past that are copied as runs after it)
+                unsigned long long const fits = __ballot(lrEnd <= 256);
+                uint32_t const lrTotal = fits ? lane_value(lrEnd, 63 - __builtin_clzll(fits)) : 0u;
+                lateRun = lateRing & (lrEnd > 256);
+                if (lrTotal && !slowWay) {
+                    tHeads[lane] = 0;
+                    if (lrLen && lrEnd <= 256) ((uint8_t*)tHeads)[lrEnd - lrLen] = (uint8_t)(lane + 1);
+                    lds_sync();
+                    uint32_t const h = tHeads[lane];
+                    uint32_t o0 = h & 0xFF, o1 = (h >> 8) & 0xFF, o2 = (h >> 16) & 0xFF, o3 = h >> 24;
+                    o1 = o1 ? o1 : o0; o2 = o2 ? o2 : o1; o3 = o3 ? o3 : o2;
+                    uint32_t const carry = wave_prev0(wave_incl_max(o3));
+                    uint32_t const own[4] = {o0 ? o0 : carry, o1 ? o1 : carry, o2 ? o2 : carry, o3 ? o3 : carry};
+                    uint32_t const packed = ((base0 + start + ll) & kWfMask) | ((lrEnd - lrLen) << 16);      // where the match goes in the ring | its first byte in the list
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        int const from = (int)(own[k] ? own[k] - 1 : 0);
+                        uint32_t const a = (uint32_t)__shfl((int)packed, from), o = (uint32_t)__shfl((int)off, from);
+                        uint32_t const e = 4 * lane + k;
+                        uint32_t const dd = ((a & 0xFFFF) + (e - (a >> 16))) & kWfMask;
+                        bool const act = e < lrTotal;
+                        late.d[k] = act ? dd : spare;
+                        late.s[k] = act ? (dd - o) & kWfMask : spare;
+                    }
+                }
+            }
+
+#ifdef ZG_STAMPS
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            z5 = __builtin_readcyclecounter();
+#endif
+            lds_sync();           // this wave's previous reads of its stages are over
+            if (litRle) *(uint4*)(litStage + 16 * lane) = make_uint4(rleFill, rleFill, rleFill, rleFill);
+            else {
+                if (lane < litFull) *(uint4*)(litStage + 16 * lane) = litV;
+                if (litFull > 64) {     // (rare: the second kilobyte)
+                    uint4 litW;
+                    __builtin_memcpy(&litW, lane + 64 < litFull ? litG + 16 * (lane + 64) : safe, 16);
+                    if (lane + 64 < litFull) *(uint4*)(litStage + 16 * (lane + 64)) = litW;
+                }
+                if (lane < litTail) litStage[16 * litFull + lane] = litT;
+            }
+            if (farFetch) { *(uint4*)(matStage + 32 * lane) = mv0; if (ml > 16) *(uint4*)(matStage + 32 * lane + 16) = mv1; }
+            lds_sync();
+            wf_copy_runs(ring, dLit, litStage + (litRle ? 0u : lstart - lit0), ll <= 32 ? ll : 0u,
+                         dMat, matStage + 32 * lane, nearNow, (uint32_t)(dMat - off), ((nearNow | farNow) & (ml <= 32)) ? ml : 0u);
+#ifdef ZG_STAMPS
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            z6 = __builtin_readcyclecounter();
+#endif
+            // ---- runs of more than 32 bytes, one after the other, by the whole wave in 16-byte pieces (the last piece ends
+            // where the run ends); a run that crosses the end of the ring goes byte by byte
+            {
+                bool const longMat = (nearNow | farNow) & (ml > 32);
+                unsigned long long lm = __ballot((ll > 32) | longMat);
+                while (lm) {
+                    int const w = __builtin_ctzll(lm);
+                    lm &= lm - 1;
+                    uint32_t const wl = lane_value(ll, w), wm = lane_value(ml, w), wo = lane_value(off, w);
+                    uint32_t const wd = lane_value(dLit, w), kind = lane_value((uint32_t)longMat | ((uint32_t)nearNow << 1), w);
+                    if (wl > 32) {
+                        uint32_t const so = lane_value(lstart - lit0, w);
+                        if (litRle) for (uint32_t c = lane; c < wl; c += 64) ring[(wd + c) & kWfMask] = (uint8_t)rleFill;
+                        else if ((wd & kWfMask) + wl > kWfRing) for (uint32_t c = lane; c < wl; c += 64) ring[(wd + c) & kWfMask] = litStage[so + c];
+                        else for (uint32_t c = 16 * lane; c < wl; c += 1024) {
+                            uint32_t const cc = c + 16 <= wl ? c : wl - 16;
+                            uint4 x;
+                            __builtin_memcpy(&x, litStage + so + cc, 16);
+                            __builtin_memcpy(ring + ((wd + cc) & kWfMask), &x, 16);
+                        }
+                    }
+                    if (kind & 1) {
+                        uint32_t const md = wd + wl;         // the match's place
+                        if (kind & 2) {     // from completed batches, ring to ring (source and destination do not overlap)
+                            uint32_t const ms0 = md - wo;
+                            if ((md & kWfMask) + wm > kWfRing || (ms0 & kWfMask) + wm > kWfRing) for (uint32_t c = lane; c < wm; c += 64) ring[(md + c) & kWfMask] = ring[(ms0 + c) & kWfMask];
+                            else for (uint32_t c = 16 * lane; c < wm; c += 1024) {
+                                uint32_t const cc = c + 16 <= wm ? c : wm - 16;
+                                uint4 x;
+                                __builtin_memcpy(&x, ring + ((ms0 + cc) & kWfMask), 16);
+                                __builtin_memcpy(ring + ((md + cc) & kWfMask), &x, 16);
+                            }
+                        } else {            // from memory
+                            const uint8_t* const g = (const uint8_t*)(uintptr_t)(((uint64_t)lane_value((uint32_t)((uintptr_t)matSrc >> 32), w) << 32) | lane_value((uint32_t)(uintptr_t)matSrc, w));
+                            if ((md & kWfMask) + wm > kWfRing) for (uint32_t c = lane; c < wm; c += 64) ring[(md + c) & kWfMask] = g[c];
+                            else for (uint32_t c = 16 * lane; c < wm; c += 1024) {
+                                uint32_t const cc = c + 16 <= wm ? c : wm - 16;
+                                uint4 x;
+                                __builtin_memcpy(&x, g + cc, 16);
+                                __builtin_memcpy(ring + ((md + cc) & kWfMask), &x, 16);
+                            }
+                        }
+                    }
+                }
+            }
+#ifdef ZG_STAMPS
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            y2 = __builtin_readcyclecounter();
+#endif
+            // ---- late part: every earlier batch is complete
+            late.pin();
+            bool const anyLateRun = __any(lateRun) != 0;
+            v4u c1;
+            WF_SPIN(uni((c1 = *(LdsQuad*)ctlMem).x) >= bt);
+#ifdef ZG_STAMPS
+            y3 = __builtin_readcyclecounter();
+#endif
+            if (stalled || uni(c1.x) != bt) break;
+            uint32_t const floor1 = uni(c1.z);
+            if (!slowWay && (floor1 == floor0 || !__any(lowSrc < floor1))) {
+                late.run_list(ring);
+                if (anyLateRun) wf_copy_runs(ring, 0u, ring, 0u, dMat, ring, true, (uint32_t)(dMat - off), lateRun ? ml : 0u);
+                late.run_deps(ring, nDeps);
+                while (depsRest) {
+                    int const w = __builtin_ctzll(depsRest);
+                    depsRest &= depsRest - 1;
+                    uint32_t const d0 = lane_value(dMat, w), o = lane_value(off, w), m = lane_value(ml, w);
+                    if (lane < m) ring[(d0 + lane) & kWfMask] = ring[(d0 - o + (o < m ? lane % o : lane)) & kWfMask];
+                }
+            } else {
+#ifdef ZG_STAMPS
+                wentSlow = 1;
+                if (!slowWay) why |= 32u;
+                if (p.dbg && lane == 0) {
+                    unsigned long long* const g = (unsigned long long*)(p.dbg + 32 * (size_t)p.nBlocks + 32 * fi);
+                    for (int k = 0; k < 6; k++) if (why >> k & 1) atomicAdd(g + 16 + k, 1ull);
+                }
+#endif
+                bool const lateNear = nearS & !nearNow & (sp >= (int64_t)floor1);
+                bool const lateFar = (farS & !farNow) | (nearS & !nearNow & !lateNear);        // (a source below a floor raised meanwhile is in memory, not in the ring)
+                bool slowNeedsMem = false;
+                if (slowS) slowNeedsMem = sp < (int64_t)floor1 || sp + (int64_t)kWfHist < (int64_t)base0;
+                if (__any(lateFar | slowNeedsMem)) {
+                    WF_SPIN(ctl[WF_FLUSHED] >= bt);
+                    // (rare: byte by byte; the conditions of `fetchable` do not all hold for a source that was near)
+                    if (lateFar) for (uint32_t j = 0; j < ml; j++) ring[(dMat + j) & kWfMask] = matSrc[j];
+                }
+                wf_copy_runs(ring, 0u, ring, 0u, dMat, ring, true, (uint32_t)(dMat - off), (lateNear & (ml <= 32)) ? ml : 0u);
+                // the dependent matches (and the long ones of the matches just copied) one after the other in sequence order: all that lies before a match is in place when
+                // its turn comes (LDS operations of a wave execute in order).  Byte j copies pattern byte j mod offset; the
+                // pattern is the `offset` bytes before the match.
+                unsigned long long sm = __ballot(slowS | (lateNear & (ml > 32)));
+                while (sm) {
+                    int const w = __builtin_ctzll(sm);
+                    sm &= sm - 1;
+                    uint32_t const d0 = lane_value(dMat, w), o = lane_value(off, w), m = lane_value(ml, w);
+                    bool const mem = lane_value((uint32_t)slowNeedsMem, w) != 0;
+                    int64_t const src0 = (int64_t)d0 - (int64_t)o;              // block-relative start of the pattern
+                    for (uint32_t j = lane; j < m; j += 64) {
+                        int64_t const q = src0 + (int64_t)(o < m ? j % o : j);
+                        uint8_t v;
+                        if (mem && (q < (int64_t)floor1 || q + (int64_t)kWfHist < (int64_t)base0)) {
+                            int64_t const a = (int64_t)bo + q;
+                            v = a >= 0 ? fdst[a] : dictEnd[a];
+                        } else v = ring[(uint32_t)q & kWfMask];
+                        ring[(d0 + j) & kWfMask] = v;
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) { v2u const w = {bt + 1, base0 + total}; *(LdsPair*)(ctlMem + WF_DONE) = w; }
+#ifdef ZG_STAMPS
+            y4 = __builtin_readcyclecounter();
+            uint64_t const prevDone = ((uint64_t)ctl[7] << 32) | ctl[6];
+            if (lane == 0) { ctl[6] = (uint32_t)y4; ctl[7] = (uint32_t)(y4 >> 32); }
+            if (p.dbg && lane == 0 && bt != 0 && prevDone) {
+                unsigned long long* const g = (unsigned long long*)(p.dbg + 32 * (size_t)p.nBlocks + 32 * fi);
+                atomicAdd(g + 14, y4 - prevDone); atomicAdd(g + 15, y3 - prevDone);
+            }
+            nLate = (uint32_t)__builtin_popcountll(__ballot(lateRing)); nSlow = (uint32_t)__builtin_popcountll(__ballot(slowS)); nFarLate = (uint32_t)__builtin_popcountll(__ballot(cls == WFC_LATE_MEMORY));
+#endif
+            // ---- flush: 16 bytes per lane at ring-aligned addresses, the ragged ends byte by byte; announced later
+            {
+                uint32_t const a0 = base0, a1 = base0 + total;
+                uint32_t const u0 = (a0 + 15) & ~15u, u1 = a1 & ~15u;
+                if (u0 <= u1) {
+                    for (uint32_t q = u0 + 16 * lane; q < u1; q += 1024) {
+                        uint4 const x = *(const uint4*)(ring + (q & kWfMask));
+                        __builtin_memcpy(bdst + q, &x, 16);
+                    }
+                    if (a0 + lane < u0) bdst[a0 + lane] = ring[(a0 + lane) & kWfMask];
+                    if (u1 + lane < a1) bdst[u1 + lane] = ring[(u1 + lane) & kWfMask];
+                } else if (a0 + lane < a1) bdst[a0 + lane] = ring[(a0 + lane) & kWfMask];
+            }
+            asm volatile("" ::: "memory");
+            flushPending = true; fpBt = bt; fpEnd = base0 + total;
+            load_recs(bt + kWf);
+#ifdef ZG_STAMPS
+            y5 = __builtin_readcyclecounter();
+            if (p.dbg && lane == 0) {
+                unsigned long long* const g = (unsigned long long*)(p.dbg + 32 * (size_t)p.nBlocks + 32 * fi);
+                atomicAdd(g + 0, y2 - y0); atomicAdd(g + 1, y3 - y2); atomicAdd(g + 2, y4 - y3); atomicAdd(g + 3, y5 - y4);
+                atomicAdd(g + 4, (unsigned long long)nHops); atomicAdd(g + 5, (unsigned long long)wentSlow);
+                atomicAdd(g + 6, 1ull); atomicAdd(g + 7, (unsigned long long)nLate); atomicAdd(g + 8, (unsigned long long)nSlow); atomicAdd(g + 9, (unsigned long long)nFarLate);
+                atomicAdd(g + 13, (unsigned long long)slowTotal);
+                atomicAdd(g + 22, z1 - y0); atomicAdd(g + 23, z2 - z1); atomicAdd(g + 24, z3 - z2); atomicAdd(g + 25, z4 - z3); atomicAdd(g + 26, z5 - z4); atomicAdd(g + 27, z6 - z5); atomicAdd(g + 28, y2 - z6);
+            }
+#endif
+        }
+        announce();
+        wf_barrier();
+        {
+            uint32_t const err = ctl[WF_ERR];
+            if (err) { ferr = err; break; }
+        }
+        if (nbSeq && nValid < nbSeq) { ferr = E_corruption; break; }
+        if (nbSeq && tailErr) { ferr = tailErr; break; }
+        {   // last literals (:1308-1317), by the whole workgroup
+            uint2 endRec = make_uint2(0, 0);
+            if (nValid) { const uint32_t* const er = (const uint32_t*)(recs + nValid); endRec = make_uint2(uni(er[1]), uni(er[2])); }
+            uint64_t const pos = endRec.x;
+            uint32_t const litPos = endRec.y;
+            uint32_t const rest = litSize - litPos;
+            if (pos > room || rest > room - pos) { ferr = E_dstSize_tooSmall; break; }
+            uint8_t* const d = bdst + pos;
+            if (litRle) { uint8_t const v = litBase[0]; for (uint32_t i = tid; i < rest; i += 64 * kWf) d[i] = v; }
+            else for (uint32_t i = tid; i < rest; i += 64 * kWf) d[i] = litBase[litPos + i];
+            produced += pos + rest;
+        }
+    }
+    if (tid == 0) { fs->regenSize = produced; fs->errorCode = ferr; }
+}
+
 // ---------------------------------------------------------------- stage 4: XXH64 + verdict
 constexpr uint64_t P1 = 0x9E3779B185EBCA87ULL, P2 = 0xC2B2AE3D27D4EB4FULL, P3 = 0x165667B19E3779F9ULL,
                    P4 = 0x85EBCA77C2B2AE63ULL, P5 = 0x27D4EB2F165667C5ULL;
@@ -2816,7 +3429,26 @@ DEVI uint64_t xxh64_group4(const uint8_t* p, uint64_t len, uint32_t gl, uint32_t
     uint64_t const stripes = len / 32;
     uint64_t v = gl == 0 ? P1 + P2 : gl == 1 ? P2 : gl == 2 ? 0 : 0 - P1;
     const uint8_t* q = p + 8 * gl;
-    for (uint64_t s = 0; s < stripes; s++, q += 32) v = xxh_round(v, ld_u64(q));
+    // The rounds of a lane depend on one another, so what a wave can hide of the memory latency is what it requests ahead:
+    // eight stripes are in flight while the eight before them are folded in.
+    uint64_t s = 0;
+    if (stripes >= 8) {
+        uint64_t cur[8], nxt[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) cur[k] = ld_u64(q + 32 * k);
+        q += 256;
+        for (s = 8; s + 8 <= stripes; s += 8, q += 256) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) nxt[k] = ld_u64(q + 32 * k);
+#pragma unroll
+            for (int k = 0; k < 8; k++) v = xxh_round(v, cur[k]);
+#pragma unroll
+            for (int k = 0; k < 8; k++) cur[k] = nxt[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) v = xxh_round(v, cur[k]);
+    }
+    for (; s < stripes; s++, q += 32) v = xxh_round(v, ld_u64(q));
     uint64_t const v1 = __shfl(v, lead), v2 = __shfl(v, lead + 1), v3 = __shfl(v, lead + 2), v4 = __shfl(v, lead + 3);
     if (len >= 32) {
         h = rotl64(v1, 1) + rotl64(v2, 7) + rotl64(v3, 12) + rotl64(v4, 18);
@@ -2948,10 +3580,23 @@ void launch_layout(const BatchParams& p, void* stream)
     if (!p.nFrames) return;
     hipLaunchKernelGGL(k_layout, dim3((p.nFrames + 63) / 64), dim3(64), 0, (hipStream_t)stream, p);
 }
-void launch_execute(const BatchParams& p, void* stream)
+// ZSTDGPU_EXECUTE=one|four in the environment sends every frame to one of the two execute kernels (tests, measurements);
+// looked up at every launch, so a test can switch between them
+static uint32_t exec_mode_env()
 {
-    if (!p.nFrames) return;
-    hipLaunchKernelGGL(k_execute, dim3(p.nFrames), dim3(64), 0, (hipStream_t)stream, p);
+    const char* const e = getenv("ZSTDGPU_EXECUTE");
+    return !e ? 0u : !strcmp(e, "one") ? 1u : !strcmp(e, "four") || !strcmp(e, "eight") ? 2u : 0u;
+}
+void launch_execute(const BatchParams& pIn, void* stream)
+{
+    if (!pIn.nFrames) return;
+    BatchParams p = pIn;
+    // Eight waves per frame pay off while the chip has room for them: two such workgroups fit a compute unit, and past
+    // four rounds of them one wave per frame (all frames resident at once) is the faster kernel.
+    uint32_t const forced = exec_mode_env();
+    p.execMode = forced ? forced : (p.nFrames > kWfMaxFrames ? 1u : 0u);
+    if (p.execMode != 1) hipLaunchKernelGGL(k_execute_wf, dim3(p.nFrames), dim3(64 * kWf), 0, (hipStream_t)stream, p);
+    if (p.execMode != 2) hipLaunchKernelGGL(k_execute, dim3(p.nFrames), dim3(64), 0, (hipStream_t)stream, p);
 }
 void launch_checksum(const BatchParams& p, void* stream)
 {
