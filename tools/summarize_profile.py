@@ -26,8 +26,12 @@ def per_kernel(path, pick):
 
 def main():
     src, tag = sys.argv[1], sys.argv[2]
+    cfg = sys.argv[3] if len(sys.argv) > 3 else "2"
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = {"tag": tag, "kernels": {}}
+    sys.path.insert(0, root)
+    import bench      # the digest of the kernel sources: bench.py takes HBM traffic from a summary only when it matches
+    out = {"tag": tag, "config": cfg, "command": f"python3 bench.py --config {cfg} --steps 5 --warmup 2 --no-cpu",
+           "kernel_source_digest": bench.kernel_source_digest(), "kernels": {}}
     stats = list(csv.DictReader(open(max(glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv")), key=os.path.getmtime))))
     for r in stats:
         if "zg::" in r["Name"]:
@@ -59,7 +63,7 @@ def main():
     with open(os.path.join(root, "profiles", f"{tag}_summary.json"), "w") as fjs:
         json.dump(out, fjs, indent=1)
     with open(os.path.join(root, "profiles", f"{tag}_summary.txt"), "w") as ft:
-        ft.write(f"rocprofv3 summary {tag}: python3 bench.py --steps 5 --warmup 2 --no-cpu (1 x MI355X)\n")
+        ft.write(f"rocprofv3 summary {tag}: {out['command']} (1 x MI355X), kernel sources {out['kernel_source_digest']}\n")
         ft.write("kernel            calls   avg_ms   fetch_MB(raw)  fetch_MB(x2)  write_MB  lds_conflict/lds_active  active  wait  stall\n")
         for k, d in sorted(out["kernels"].items(), key=lambda kv: -kv[1]["avg_ns"]):
             ft.write("%-16s %6d %8.4f %13.1f %13.1f %9.1f   %10.0f/%-12.0f %6.2f %5.2f %5.2f\n" % (
