@@ -90,11 +90,17 @@ def test_divergent_fixtures_every_verdict(e):
         assert verdict_of(*oracle.decompress(fr, e["capacity"])) == e["build"]
         if e["class"] != "legacy_magic":
             assert e["build"] == e["zstd148"]
-        oracle.set_body(oracle.BODY_ALWAYS_PREFETCHING)
-        assert verdict_of(*oracle.decompress(fr, e["capacity"])) == e["as_written"]
+        if "as_written" in e:
+            oracle.set_body(oracle.BODY_ALWAYS_PREFETCHING)
+            assert verdict_of(*oracle.decompress(fr, e["capacity"])) == e["as_written"]
+        if "never_prefetching" in e:      # frames that zstd 1.4.8 itself hands to its prefetching loop (window above 2^24)
+            oracle.set_body(oracle.BODY_NEVER_PREFETCHING)
+            assert verdict_of(*oracle.decompress(fr, e["capacity"])) == e["never_prefetching"]
+            assert e["never_prefetching"] != e["build"]
         oracle.set_body(oracle.BODY_AS_ZSTD_148)
-        oracle.set_huf(1)
-        assert verdict_of(*oracle.decompress(fr, e["capacity"])) == e["x1_only"]
+        if "x1_only" in e:
+            oracle.set_huf(1)
+            assert verdict_of(*oracle.decompress(fr, e["capacity"])) == e["x1_only"]
     finally:
         oracle.set_body(oracle.BODY_AS_ZSTD_148)
         oracle.set_huf(0)

@@ -37,7 +37,7 @@ DEVI void walk_frame(const uint8_t* base, uint64_t srcBytes, FrameIn const in, u
                      DevFrame& f, uint32_t& slots, Emit emit)
 {
     f.dstOff = in.dstOff; f.dstCapacity = in.dstCapacity; f.contentSize = kContentSizeUnknown;
-    f.firstBlock = 0; f.nBlocks = 0; f.checksumFlag = 0; f.checksum = 0; f.hostError = 0; f.useDict = opts & kOptDict;
+    f.firstBlock = 0; f.nBlocks = 0; f.checksumFlag = 0; f.checksum = 0; f.hostError = 0; f.useDict = opts & kOptDict; f.longWindow = 0; f.pad = 0;
     uint32_t const pre = (opts & kOptMagicless) ? 1u : 5u;      // bytes up to and including the descriptor byte
     slots = 0;
     if (in.srcOff > srcBytes || in.srcSize > srcBytes - in.srcOff) { f.hostError = E_srcSize_wrong; return; }
@@ -52,9 +52,12 @@ DEVI void walk_frame(const uint8_t* base, uint64_t srcBytes, FrameIn const in, u
     if (pre == 5 && g32(src) != kMagic) { f.hostError = E_prefix_unknown; return; }
     if (fhd & 0x08) { f.hostError = E_frameParameter_unsupported; return; }
     uint32_t pos = pre;
+    uint64_t windowSize = 0;
     if (!singleSegment) {
         uint32_t const wl = src[pos++];
         if ((wl >> 3) + 10 > kWindowLogMax) { f.hostError = E_frameParameter_windowTooLarge; return; }
+        windowSize = 1ull << ((wl >> 3) + 10);
+        windowSize += (windowSize >> 3) * (wl & 7);
     }
     uint32_t dictID = 0;
     if (dictIDSizeCode == 1) { dictID = src[pos]; pos += 1; }
@@ -66,6 +69,8 @@ DEVI void walk_frame(const uint8_t* base, uint64_t srcBytes, FrameIn const in, u
     else if (fcsID == 2) contentSize = g32(src + pos);
     else contentSize = g64(src + pos);
     f.contentSize = contentSize;
+    if (singleSegment) windowSize = contentSize;          // zstd_decompressf.pas:375
+    f.longWindow = windowSize > (1ull << 24) ? 1u : 0u;
     uint64_t ip = fhsize;
     remaining -= fhsize;
     bool stopped = false;
@@ -96,7 +101,7 @@ DEVI void walk_frame(const uint8_t* base, uint64_t srcBytes, FrameIn const in, u
     if (ip != in.srcSize && f.checksumFlag != 2 && !stopped) f.hostError = E_srcSize_wrong;
     if (!f.hostError && dictID && dictID != batchDictID) f.hostError = E_dictionary_wrong;     // ZSTD_decodeFrameHeader :541-563
     if (!f.hostError && f.dstCapacity > 0x7FFFFFFEull) f.dstCapacity = 0x7FFFFFFEull;           // frames regenerate < 2 GiB
-    if (f.hostError) f.nBlocks = 0;
+    if (f.hostError) { f.nBlocks = 0; f.longWindow = 0; }
 }
 
 // Literals-section header and the count / modes bytes of the sequences section of one compressed block.

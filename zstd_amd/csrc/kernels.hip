@@ -1635,6 +1635,21 @@ constexpr uint32_t kSlot0 = kSymbolicRep | (0u << kRepIdxShift), kSlot1 = kSymbo
 // is mirrored behind slot 127 so that a peek never wraps.  While round k+1 is decoded, the helpers that work on
 // round k fetch the units below (cursor after round k) - 80 units; the chain stops a round early in the
 // (pathological) case that it would pass the loaded floor.
+// Whether zstd 1.4.8 decodes a block's sequences with its prefetching loop (ZSTD_decompressSequencesLong) rather than
+// the regular one: only in frames with a window above 2^24, for blocks of more than 4 sequences whose offset table has
+// at least 7/256 of its cells with more than 22 additional bits (ZSTD_getLongOffsetsShare, zstd_decompress_block.pas:1460-1488,
+// dispatch :1527-1541).  The two loops regenerate the same bytes from a sound stream and differ on a damaged one: the
+// prefetching loop stops with corruption_detected once the stream has run dry with sequences left (:1376-1400), and does
+// not check that the stream was used up.
+template <typename CellPtr>
+DEVI bool prefetching_loop_148(uint32_t longWindow, uint32_t nbSeq, CellPtr tOF, uint32_t logOF)
+{
+    if (!longWindow || nbSeq <= 4) return false;
+    uint32_t total = 0;
+    for (uint32_t u = 0; u < (1u << logOF); u++) total += cell_addBits(T_OF, tOF[u]) > 22 ? 1u : 0u;
+    return (total << (8 - logOF)) >= 7;
+}
+
 struct SeqCtl {            // per block, in LDS
     uint32_t fail, nbSeq, logs, Qinit, Qstart;      // logs = logLL | logOF << 8 | logML << 16
 };
@@ -2076,8 +2091,11 @@ __global__ __launch_bounds__(kSeqThreads) void k_sequences(BatchParams p)
             // answering from the last container (bitstream.pas:300-314).  Such blocks (damaged input only) are decoded
             // again, serially and to the letter, by k_sequences_dry.
             if (nValid < nbSeq) { uint32_t const at = atomicAdd(p.dryList, 1u); p.dryList[1 + at] = b; }
-            // after the last sequence the reader must be at (or, through the last state update, past) the stream start (:1301)
-            st->tailErr = (nValid == nbSeq && (int)Qend > (int)Qstart) ? (uint32_t)E_corruption : 0u;
+            // after the last sequence the reader must be at (or, through the last state update, past) the stream start (:1301);
+            // the prefetching loop of 1.4.8 has no such check
+            bool unfinished = nValid == nbSeq && (int)Qend > (int)Qstart;
+            if (unfinished && prefetching_loop_148(p.frames[blk.frameIdx].longWindow, nbSeq, tOF, (ctl[slot].logs >> 8) & 255)) unfinished = false;
+            st->tailErr = unfinished ? (uint32_t)E_corruption : 0u;
             st->regen = (uint64_t)outPos + (litPos <= blk.litSize ? blk.litSize - litPos : 0);
             st->repOut[0] = rep.a; st->repOut[1] = rep.b; st->repOut[2] = rep.c;
         }
@@ -2186,7 +2204,12 @@ __global__ __launch_bounds__(64) void k_sequences_dry(BatchParams p)
         uint32_t sML = bs.read(logML); bs.reload();
         Rep3 rep = {kSlot0, kSlot1, kSlot2};
         uint32_t outPos = 0, litPos = 0;
+        // the prefetching loop looks at the stream before it decodes a sequence and stops when it has overflowed
+        // (:1347, :1376); firstDry = the first sequence that finds it so
+        bool const prefetching = prefetching_loop_148(p.frames[blk.frameIdx].longWindow, blk.nbSeq, tOF, logOF);
+        uint32_t firstDry = blk.nbSeq;
         for (uint32_t n = 0; n < blk.nbSeq; n++) {
+            if (prefetching && firstDry == blk.nbSeq && bs.reload() == 3) firstDry = n;
             uint32_t const cLL = tLL[sLL], cML = tML[sML], cOF = tOF[sOF];
             uint32_t const ofBits = cell_addBits(T_OF, cOF), mlBits = cell_addBits(T_ML, cML), llBits = cell_addBits(T_LL, cLL);
             uint32_t const llCode = cell_llCode(cLL), mlCode = cell_mlCode(cML);
@@ -2222,8 +2245,16 @@ __global__ __launch_bounds__(64) void k_sequences_dry(BatchParams p)
         }
         out[blk.nbSeq] = make_uint4(0, outPos, litPos, 0);
         st->seqErr = 0;
-        st->seqValid = blk.nbSeq;
-        st->tailErr = bs.reload() < 2 ? (uint32_t)E_corruption : 0u;       // (:1301)
+        if (prefetching) {
+            // Executed before the loop gave up: the sequences up to four before the one that found the stream dry (the
+            // loop decodes four ahead of the one it executes, :1341-1400); an error of theirs comes first, else the
+            // missing sequences make the block corruption_detected.  No check of what is left of the stream.
+            st->seqValid = firstDry == blk.nbSeq ? blk.nbSeq : firstDry >= 4 ? firstDry - 4 : 0u;
+            st->tailErr = 0;
+        } else {
+            st->seqValid = blk.nbSeq;
+            st->tailErr = bs.reload() < 2 ? (uint32_t)E_corruption : 0u;       // (:1301)
+        }
         st->regen = (uint64_t)outPos + (litPos <= blk.litSize ? blk.litSize - litPos : 0);
         st->repOut[0] = rep.a; st->repOut[1] = rep.b; st->repOut[2] = rep.c;
     }

@@ -608,10 +608,11 @@ extern "C" zstdgpu_batch* zstdgpu_batch_create(zstdgpu_ctx* ctx, const void* hos
         f.checksumFlag = fd.checksumFlag; f.checksum = fd.checksum;
         f.hostError = fd.hostError;
         f.useDict = ddict ? 1 : 0;
+        f.longWindow = fd.windowSize > (1ull << 24) ? 1 : 0;
         if (!f.hostError && fd.dictID && fd.dictID != batchDictID) f.hostError = E_dictionary_wrong;
         if (!f.hostError && (uint64_t)fd.firstBlock + fd.nBlocks > nBlocks) f.hostError = E_generic;
         if (!f.hostError && fd.dstCapacity > 0x7FFFFFFEull) f.dstCapacity = 0x7FFFFFFEull;   // frames regenerate < 2 GiB (the port's sizes are int32)
-        if (f.hostError) { f.nBlocks = 0; continue; }
+        if (f.hostError) { f.nBlocks = 0; f.longWindow = 0; continue; }
         B->srcBytes += fd.srcSize;
         // entropy state carried from block to block inside the frame (zstd_ddict.pas:109-126): which block defines each table
         int32_t hufDef = dictEntropy ? SRC_DICT : SRC_NONE;

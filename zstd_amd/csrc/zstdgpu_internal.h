@@ -73,7 +73,10 @@ struct DevFrame {
     uint32_t checksumFlag, checksum;
     uint32_t hostError;
     uint32_t useDict;      // 1: the batch dictionary applies to this frame
+    uint32_t longWindow;   // 1: window above 2^24 -- zstd 1.4.8 may run its prefetching sequence loop on this frame's blocks
+    uint32_t pad;          // (zero: the descriptor digest covers every byte)
 };
+static_assert(sizeof(DevFrame) == 56, "no implicit padding in DevFrame");
 
 struct DevFrameStatus {    // same layout as zstdgpu_frame_status
     uint32_t errorCode, xxh64Low32;
