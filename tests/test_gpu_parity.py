@@ -277,15 +277,27 @@ def test_destroy_without_status_then_next_batch(dctx):
 def test_context_closed_before_its_children():
     """zstdgpu_destroy with a dictionary and a stream still alive: freeing them afterwards is harmless, and the orphaned
     stream refuses work."""
+    import torch
     d = api.DCtx(0)
     dd = api.DDict(d, read_dict("dict16k"))
     zs = api.DStream(d)
+    e = next(x for x in FRAMES if x["name"] == "text4096_l3_c1")
+    src, fin, dst_bytes = api.pack_frames([read_frame(e)] * 3, [e["capacity"]] * 3)
+    b = api.Batch(d, src, fin)
     d.close()
     with pytest.raises(api.ZstdError) as ex:
         zs.decompress_stream(b"\x28\xb5\x2f\xfd", 16)
     assert ex.value.code == 60
     zs.close()
     dd.close()
+    # a batch outlives its context too: it still decodes, and frees what it holds itself
+    d_src = torch.from_numpy(src).cuda()
+    d_dst = torch.zeros(dst_bytes, dtype=torch.uint8, device="cuda")
+    b.decode(d_src.data_ptr(), d_dst.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    st = b.status()
+    assert [int(x) for x in st["errorCode"]] == [0, 0, 0]
+    assert d_dst[: e["size"]].cpu().numpy().tobytes() == regenerate(e["source"])
+    b.close()
 
 
 def test_init_stream_cannot_swap_the_dictionary_under_a_busy_stream(dctx):

@@ -159,7 +159,8 @@ size_t walk_frame(const uint8_t* base, const zstdgpu_frame_in& in, uint32_t fram
 
 // ===================================================================== objects (context and dictionary: zstdgpu_objects.h)
 struct zstdgpu_batch {
-    zstdgpu_ctx* ctx = nullptr;
+    zstdgpu_ctx* ctx = nullptr;      // null once the context is gone: the batch still decodes and frees what it holds
+    int device = 0;
     const zstdgpu_ddict* ddict = nullptr;
     std::vector<DevBlock> hBlocks;
     std::vector<DevFrame> hFrames;
@@ -184,6 +185,7 @@ struct zstdgpu_batch {
 namespace {
 
 bool set_device(const zstdgpu_ctx* ctx) { return hipSetDevice(ctx->device) == hipSuccess; }
+bool set_device(const zstdgpu_batch* b);
 
 template <typename T>
 bool dalloc(T*& p, size_t n, uint64_t& acct)
@@ -216,7 +218,7 @@ bool balloc(zstdgpu_ctx* ctx, T*& p, size_t n, size_t& got, uint64_t& acct)
 void bfree(zstdgpu_ctx* ctx, void* p, size_t bytes)
 {
     if (!p) return;
-    if (bytes >= (1u << 20) && ctx->spare.size() < 16) ctx->spare.push_back({p, bytes});    // small buffers are cheap to allocate again
+    if (ctx && bytes >= (1u << 20) && ctx->spare.size() < 16) ctx->spare.push_back({p, bytes});    // small buffers are cheap to allocate again
     else hipFree(p);
 }
 
@@ -278,6 +280,24 @@ void parse_sections(const uint8_t* payload, DevBlock& d)
     d.llType = *ip >> 6; d.ofType = (*ip >> 4) & 3; d.mlType = (*ip >> 2) & 3;
     ip++;
     d.seqHdrOff = (uint32_t)(ip - payload);
+}
+
+bool set_device(const zstdgpu_batch* b) { return hipSetDevice(b->device) == hipSuccess; }
+
+// A batch is known to its context so that a context destroyed first can tell it (zstdgpu_destroy).
+bool adopt_batch(zstdgpu_ctx* ctx, zstdgpu_batch* b)
+{
+    b->ctx = ctx; b->device = ctx->device;
+    try { ctx->batches.push_back(b); } catch (...) { b->ctx = nullptr; return false; }
+    return true;
+}
+void drop_batch(zstdgpu_batch* b)
+{
+    if (b->ctx) {
+        auto& v = b->ctx->batches;
+        for (size_t i = 0; i < v.size(); i++) if (v[i] == b) { v.erase(v.begin() + (long)i); break; }
+    }
+    delete b;
 }
 
 void free_batch_device(zstdgpu_batch* b)
@@ -344,6 +364,7 @@ extern "C" void zstdgpu_destroy(zstdgpu_ctx* ctx)
     // dictionaries and streams that outlive the context keep working as far as they can: they forget it
     for (auto* z : ctx->streams) stream_detach(z);
     for (auto* d : ctx->ddicts) d->ctx = nullptr;
+    for (auto* b : ctx->batches) b->ctx = nullptr;
     hipFree(ctx->dSrc); hipFree(ctx->dDst);
     for (auto& sp : ctx->spare) hipFree(sp.p);
     delete ctx;
@@ -592,7 +613,8 @@ extern "C" zstdgpu_batch* zstdgpu_batch_create(zstdgpu_ctx* ctx, const void* hos
     if (!ctx || !set_device(ctx)) return nullptr;
     zstdgpu_batch* B = new (std::nothrow) zstdgpu_batch;
     if (!B) return nullptr;
-    B->ctx = ctx; B->ddict = ddict;
+    if (!adopt_batch(ctx, B)) { delete B; return nullptr; }
+    B->ddict = ddict;
     const uint8_t* const src = (const uint8_t*)hostSrc;
     bool const dictEntropy = ddict && ddict->hasEntropy;
     uint32_t const batchDictID = ddict ? ddict->dictID : 0;
@@ -651,7 +673,7 @@ extern "C" zstdgpu_batch* zstdgpu_batch_create(zstdgpu_ctx* ctx, const void* hos
             }
         }
     }
-    } catch (...) { delete B; return nullptr; }      // the C ABI never throws
+    } catch (...) { drop_batch(B); return nullptr; }      // the C ABI never throws
     B->litBytes = litOff + 64; B->nSeqTotal = seqOff;
     B->nFrames = nFrames; B->nBlocks = nBlocks; B->nLitJobs = (uint32_t)B->hLitJobs.size(); B->nSeqJobs = (uint32_t)B->hSeqJobs.size();
     bool ok = dalloc(B->dBlocks, nBlocks, B->scratchBytes) && dalloc(B->dState, nBlocks, B->scratchBytes) &&
@@ -664,7 +686,7 @@ extern "C" zstdgpu_batch* zstdgpu_batch_create(zstdgpu_ctx* ctx, const void* hos
          up(B->dLitJobs, B->hLitJobs.data(), B->hLitJobs.size() * 4) && up(B->dSeqJobs, B->hSeqJobs.data(), B->hSeqJobs.size() * 4);
     ok = ok && hipStreamCreateWithFlags(&B->side, hipStreamNonBlocking) == hipSuccess &&
          hipEventCreateWithFlags(&B->evFork, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&B->evJoin, hipEventDisableTiming) == hipSuccess;
-    if (!ok) { free_batch_device(B); delete B; return nullptr; }
+    if (!ok) { free_batch_device(B); drop_batch(B); return nullptr; }
     return B;
 }
 
@@ -693,7 +715,8 @@ extern "C" zstdgpu_batch* zstdgpu_batch_create_on_device(zstdgpu_ctx* ctx, const
     if (!ctx || !set_device(ctx) || (nFrames && (!in || !devSrc))) return nullptr;
     zstdgpu_batch* B = new (std::nothrow) zstdgpu_batch;
     if (!B) return nullptr;
-    B->ctx = ctx; B->ddict = ddict;
+    if (!adopt_batch(ctx, B)) { delete B; return nullptr; }
+    B->ddict = ddict;
     uint32_t const batchDictID = ddict ? ddict->dictID : 0;
     FrameIn* dIn = nullptr; uint32_t* dSlots = nullptr; uint64_t* dTotals = nullptr; uint8_t* dFlags = nullptr;
     uint64_t tmpAcct = 0;
@@ -730,7 +753,7 @@ extern "C" zstdgpu_batch* zstdgpu_batch_create_on_device(zstdgpu_ctx* ctx, const
     ok = ok && hipStreamCreateWithFlags(&B->side, hipStreamNonBlocking) == hipSuccess &&
          hipEventCreateWithFlags(&B->evFork, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&B->evJoin, hipEventDisableTiming) == hipSuccess;
     cleanup();
-    if (!ok) { free_batch_device(B); delete B; return nullptr; }
+    if (!ok) { free_batch_device(B); drop_batch(B); return nullptr; }
     return B;
 }
 
@@ -738,7 +761,7 @@ extern "C" zstdgpu_batch* zstdgpu_batch_create_on_device(zstdgpu_ctx* ctx, const
 static bool mirror(zstdgpu_batch* B)
 try {
     if (B->mirrored) return true;
-    if (!set_device(B->ctx)) return false;
+    if (!set_device(B)) return false;
     B->hBlocks.resize(B->nBlocks); B->hFrames.resize(B->nFrames); B->hLitJobs.resize(B->nLitJobs); B->hSeqJobs.resize(B->nSeqJobs);
     auto down = [&](void* h, const void* d, size_t n) { return n == 0 || hipMemcpy(h, d, n, hipMemcpyDeviceToHost) == hipSuccess; };
     bool const ok = down(B->hBlocks.data(), B->dBlocks, (size_t)B->nBlocks * sizeof(DevBlock)) && down(B->hFrames.data(), B->dFrames, (size_t)B->nFrames * sizeof(DevFrame)) &&
@@ -766,14 +789,14 @@ extern "C" uint64_t zstdgpu_batch_descriptorDigest(zstdgpu_batch* b)
 extern "C" void zstdgpu_batch_destroy(zstdgpu_batch* b)
 {
     if (!b) return;
-    set_device(b->ctx);
+    set_device(b);
     free_batch_device(b);
-    delete b;
+    drop_batch(b);
 }
 
 extern "C" size_t zstdgpu_batch_decode(zstdgpu_batch* B, const void* devSrc, void* devDst, void* stream)
 {
-    if (!B || !set_device(B->ctx)) return mkerr(E_generic);
+    if (!B || !set_device(B)) return mkerr(E_generic);
     hipStream_t const s = (hipStream_t)stream;
     BatchParams p{};
     p.src = (const uint8_t*)devSrc; p.dst = (uint8_t*)devDst;
@@ -856,7 +879,7 @@ extern "C" size_t zstdgpu_batch_decode(zstdgpu_batch* B, const void* devSrc, voi
 
 extern "C" size_t zstdgpu_batch_status(zstdgpu_batch* B, zstdgpu_frame_status* status)
 {
-    if (!B || !set_device(B->ctx)) return mkerr(E_generic);
+    if (!B || !set_device(B)) return mkerr(E_generic);
     if (hipStreamSynchronize(B->lastStream) != hipSuccess) return mkerr(E_generic);
     static_assert(sizeof(zstdgpu_frame_status) == sizeof(DevFrameStatus), "status layout");
     if (status && B->nFrames &&
@@ -872,7 +895,7 @@ extern "C" uint64_t zstdgpu_batch_scratchBytes(const zstdgpu_batch* b) { return 
 
 extern "C" void zstdgpu_batch_set_profiling(zstdgpu_batch* B, int enabled)
 {
-    if (!B || !set_device(B->ctx)) return;
+    if (!B || !set_device(B)) return;
     if (enabled && !B->evReady) {
         bool ok = true;
         for (auto& e : B->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
@@ -883,7 +906,7 @@ extern "C" void zstdgpu_batch_set_profiling(zstdgpu_batch* B, int enabled)
 }
 extern "C" size_t zstdgpu_batch_stage_ms(zstdgpu_batch* B, float* ms)
 {
-    if (!B || !B->evRecorded || !set_device(B->ctx)) return mkerr(E_generic);
+    if (!B || !B->evRecorded || !set_device(B)) return mkerr(E_generic);
     if (hipEventSynchronize(B->ev[5]) != hipSuccess) return mkerr(E_generic);
     for (int i = 0; i < 5; i++) if (hipEventElapsedTime(&ms[i], B->ev[i], B->ev[i + 1]) != hipSuccess) return mkerr(E_generic);
     if (hipEventElapsedTime(&ms[ZSTDGPU_STAGE_TOTAL], B->ev[0], B->ev[5]) != hipSuccess) return mkerr(E_generic);
@@ -927,7 +950,7 @@ extern "C" size_t zstdgpu_predefinedTables(zstdgpu_ctx* ctx, uint32_t* cells)
 
 extern "C" size_t zstdgpu_batch_blockInfo(zstdgpu_batch* B, uint32_t bi, uint32_t* litSize, uint32_t* nbSeq, uint64_t* regenSize, uint32_t* errorCode)
 {
-    if (!B || bi >= B->nBlocks || !set_device(B->ctx) || !mirror(B)) return mkerr(E_generic);
+    if (!B || bi >= B->nBlocks || !set_device(B) || !mirror(B)) return mkerr(E_generic);
     if (hipStreamSynchronize(B->lastStream) != hipSuccess) return mkerr(E_generic);
     DevBlockState st;
     if (hipMemcpy(&st, B->dState + bi, sizeof(st), hipMemcpyDeviceToHost) != hipSuccess) return mkerr(E_generic);
@@ -941,7 +964,7 @@ extern "C" size_t zstdgpu_batch_blockInfo(zstdgpu_batch* B, uint32_t bi, uint32_
 
 extern "C" size_t zstdgpu_batch_copyLiterals(zstdgpu_batch* B, const void* devSrc, uint32_t bi, void* out, size_t cap)
 {
-    if (!B || bi >= B->nBlocks || !set_device(B->ctx) || !mirror(B)) return mkerr(E_generic);
+    if (!B || bi >= B->nBlocks || !set_device(B) || !mirror(B)) return mkerr(E_generic);
     if (hipStreamSynchronize(B->lastStream) != hipSuccess) return mkerr(E_generic);
     const DevBlock& d = B->hBlocks[bi];
     if (d.blockType != BT_COMPRESSED || d.hostLitErr) return mkerr(E_generic);
@@ -961,7 +984,7 @@ extern "C" size_t zstdgpu_batch_copyLiterals(zstdgpu_batch* B, const void* devSr
 
 extern "C" size_t zstdgpu_batch_copySequences(zstdgpu_batch* B, uint32_t bi, uint32_t* triples, size_t tripleCapacity)
 try {
-    if (!B || bi >= B->nBlocks || !set_device(B->ctx) || !mirror(B)) return mkerr(E_generic);
+    if (!B || bi >= B->nBlocks || !set_device(B) || !mirror(B)) return mkerr(E_generic);
     if (hipStreamSynchronize(B->lastStream) != hipSuccess) return mkerr(E_generic);
     const DevBlock& d = B->hBlocks[bi];
     if (d.blockType != BT_COMPRESSED || d.hostLitErr || d.hostSeqErr) return mkerr(E_generic);

@@ -26,6 +26,7 @@ struct zstdgpu_ctx {
     const zstdgpu_ddict* refDDict = nullptr;
     std::vector<zstdgpu_dstream*> streams;        // streams opened on this context
     std::vector<zstdgpu_ddict*> ddicts;           // dictionaries created on it (they forget it when it is destroyed)
+    std::vector<zstdgpu_batch*> batches;          // batches created on it (likewise)
     uint8_t* scratch = nullptr;                   // this device's fixed scratch array (zstdgpu_decode_frames_noalloc)
     uint32_t opts() const { return (format ? zg::kOptMagicless : 0u) | (ignoreChecksum ? zg::kOptIgnoreChecksum : 0u); }
     void reset_parameters() { format = 0; maxWindowSize = (1ull << 27) + 1; stableOut = 0; ignoreChecksum = 0; }
