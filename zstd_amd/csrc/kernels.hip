@@ -1888,7 +1888,9 @@ __global__ __launch_bounds__(kSeqThreads) void k_sequences(BatchParams p)
                     // Software pipeline: the cell of the next sequence is requested as soon as its state is known, and the
                     // bookkeeping (ring entry, cursor, window request for the next sequence) runs while that read is in flight.
                     auto win_read = [&](uint32_t T, uint32_t& a0, uint32_t& a1, uint32_t& a2, uint32_t& a3) {
-                        lds_u32 const w = (lds_u32)(uintptr_t)(winL + 4 * __builtin_amdgcn_ubfe(T, 5, 9));
+                        uint32_t word = __builtin_amdgcn_ubfe(T, 5, 9);
+                        asm volatile("" : "+v"(word));      // (a field extract and a shift-add: kept from being turned into three instructions)
+                        lds_u32 const w = (lds_u32)(uintptr_t)(winL + 4 * word);
                         a0 = w[0]; a1 = w[1]; a2 = w[2]; a3 = w[3];
                     };
                     // 96 bits below the cursor (top at Q + 1, so that the state bits of any sequence start inside them)
@@ -1898,6 +1900,7 @@ __global__ __launch_bounds__(kSeqThreads) void k_sequences(BatchParams p)
 #ifdef ZG_STAMPS
                     uint64_t const kl0 = __builtin_readcyclecounter();
 #endif
+                    uint32_t ringP = ringL;        // ring entry of the group's first sequence: the eight stores of a group go to it + constants
                     for (; i < kSeqRound; i += 8) {
                         if (T < Tlim) break;
                         // Past the block's last sequence the chain runs on over bits that mean nothing, inside the window
@@ -1925,12 +1928,16 @@ __global__ __launch_bounds__(kSeqThreads) void k_sequences(BatchParams p)
                             uint32_t const cn = *(lds_u32)(uintptr_t)(tabL + 4 * st);
                             __builtin_amdgcn_sched_barrier(0);
                             uint32_t const Tprev = T;
-                            T = T + R - 63u - __builtin_amdgcn_ubfe(S, 21, 5);       // additional bits: 63 - R
+                            uint32_t Tm = T + R + 0xFFFFFFC1u;      // additional bits: 63 - R
+                            asm volatile("" : "+v"(Tm));            // (one three-operand add)
+                            T = Tm - __builtin_amdgcn_ubfe(S, 21, 5);
                             win_read(T, a0, a1, a2, a3);
-                            *(lds_u32w)(uintptr_t)(ringL + 16 * (i + j)) = role == 3 ? Tprev : c;
+                            *(lds_u32w)(uintptr_t)(ringP + 16 * j) = role == 3 ? Tprev : c;
                             c = cn;
                             __builtin_amdgcn_sched_barrier(0);
                         }
+                        ringP += 16 * 8;
+                        asm volatile("" : "+v"(ringP));
                     }
 #ifdef ZG_STAMPS
                     kLoop += __builtin_readcyclecounter() - kl0; kRounds++;
@@ -2714,8 +2721,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
             uint4 litV, mv0, mv1;
             __builtin_memcpy(&litV, (stagedLit && lane < litFull) ? litG + 16 * lane : safe, 16);
             uint8_t const litT = *((stagedLit && lane < litTail) ? litG + 16 * litFull + lane : safe);
+#ifdef ZG_X_NOFAR     // experiment (wrong output): what the scattered match-source fetches cost
+            __builtin_memcpy(&mv0, safe, 16);
+            __builtin_memcpy(&mv1, safe, 16);
+#else
             __builtin_memcpy(&mv0, fastLen ? matSrc : safe, 16);
             __builtin_memcpy(&mv1, fastLen > 16 ? matSrc + 16 : safe, 16);
+#endif
             uint32_t gdst = 0xFFFFFFFFu;
             const uint8_t* gsrc = safe;
             {
@@ -2762,8 +2774,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
                 x3 = __builtin_readcyclecounter();
 #endif
                 lds_sync();
+#ifndef ZG_X_NORUNS
                 lds_copy_runs(outB + start, litStage + (litRle ? 0u : lstart - lit0), ll,
                               outB + start + ll, nearS ? outB + start + ll - off : matStage + 32 * lane, nearS ? ml : fastLen);
+#endif
                 if (gdst != 0xFFFFFFFFu) outB[gdst] = gv;
 #ifdef ZG_STAMPS
                 xa = __builtin_readcyclecounter();
@@ -2774,13 +2788,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
                 // (LDS operations of a wave execute in order: a read sees the writes issued before it.)
                 {
                     unsigned long long sm = __ballot(slowS != 0);
+#ifdef ZG_X_NOSLOW
+                    sm = 0;
+#endif
                     while (sm) {
                         int const w = __builtin_ctzll(sm);
                         sm &= sm - 1;
                         uint32_t const d0 = lane_value(start + ll, w), o = lane_value(off, w), m = lane_value(ml, w), g = lane_value(gcnt, w);
                         if (o < m) {
+                            // (j mod o by a reciprocal: j, o < 2^12, the quotient estimate is off by one at most)
+                            float const ro = __builtin_amdgcn_rcpf((float)o);
                             for (uint32_t j = g + lane; j < m; j += 64) {
-                                uint32_t const q = j % o;
+                                uint32_t q = j - (uint32_t)((float)j * ro) * o;
+                                q = (int32_t)q < 0 ? q + o : q;
+                                q = q >= o ? q - o : q;
                                 outB[d0 + j] = outB[q < g ? d0 + q : d0 - o + q];
                             }
                         } else {
@@ -2795,7 +2816,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
                 // ---- the batch's output, contiguous: 16 bytes per lane, then the last bytes one per lane
                 {
                     uint8_t* const d0 = fdst + bo + base0;
+#ifdef ZG_X_NOSTORE
+                    uint32_t const full = 0, tail = 0;
+#else
                     uint32_t const full = total >> 4, tail = total & 15;
+#endif
                     for (uint32_t u = lane; u < full; u += 64) {
                         uint4 x;
                         __builtin_memcpy(&x, outB + 16 * u, 16);
