@@ -3244,9 +3244,6 @@ __global__ __launch_bounds__(64 * kWf) __attribute__((amdgpu_waves_per_eu(4))) v
             // 4l .. 4l+3 of their concatenation).  Each such match marks its first byte with its lane; a prefix maximum
             // carries the marks forward.
             bool lateRun = false;
-#ifdef ZG_WF_NOLIST
-            lateRun = lateRing;
-#else
             {
                 uint32_t const lrLen = lateRing ? ml : 0;
                 uint32_t const lrEnd = wave_incl_scan(lrLen);
@@ -3276,7 +3273,6 @@ __global__ __launch_bounds__(64 * kWf) __attribute__((amdgpu_waves_per_eu(4))) v
                     }
                 }
             }
-#endif
 
 #ifdef ZG_STAMPS
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
