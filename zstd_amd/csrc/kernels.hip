@@ -651,8 +651,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
     if (ok) {
         // table fill (HUF_readDTableX1_wksp second half): cell = {symbol, nbBits = tableLog + 1 - weight}
         if (fromDict) {
-            uint32_t const n = 1u << tableLog;
-            for (uint32_t u = sl; u < n; u += kHufLanes) x1[u] = p.dict->huf[u];
+            // 16 bytes per lane and pass, four passes' loads ahead of their stores (both arrays hold 4096 cells and are
+            // 16-byte aligned: a short table is copied rounded up)
+            uint32_t const units = ((2u << tableLog) + 15) >> 4;
+            const uint4* const from = (const uint4*)p.dict->huf;
+            uint4* const to = (uint4*)x1;
+            for (uint32_t u = sl; u < units; u += 4 * kHufLanes) {
+                uint32_t const u1 = u + kHufLanes < units ? u + kHufLanes : u, u2 = u + 2 * kHufLanes < units ? u + 2 * kHufLanes : u,
+                               u3 = u + 3 * kHufLanes < units ? u + 3 * kHufLanes : u;
+                uint4 const x0 = from[u], x1 = from[u1], x2 = from[u2], x3 = from[u3];
+                to[u] = x0; to[u1] = x1; to[u2] = x2; to[u3] = x3;
+            }
         } else {
             for (uint32_t n = sl; n < nbSymbols; n += kHufLanes) {
                 uint32_t const w = weights[n];
@@ -1781,8 +1790,21 @@ __global__ __launch_bounds__(kSeqThreads) void k_sequences(BatchParams p)
                 if (kind == TK_FAIL) fail = true;
                 else if (kind == TK_NORM) grp_build_seq_table(t, cells, norm, maxSV, lg, bscr, gl, sLLbits, sMLbits);
                 else if (kind == TK_DICT) {
-                    const uint32_t* const dc = t == T_LL ? p.dict->ll : t == T_OF ? p.dict->of : p.dict->ml;
-                    for (uint32_t u = gl; u < (1u << lg); u += 16) cells[u] = dc[u];
+                    // (16 bytes per lane and pass, the loads of eight passes -- a whole table of 512 cells -- ahead of the stores;
+                    // source and destination hold at least 256 cells and are 16-byte aligned: a short table is copied rounded up)
+                    const uint4* const dc = (const uint4*)(t == T_LL ? p.dict->ll : t == T_OF ? p.dict->of : p.dict->ml);
+                    uint4* const to = (uint4*)cells;
+                    uint32_t const units = ((4u << lg) + 15) >> 4;
+                    // (a lane with no piece left in a pass copies the table's last piece again: the pieces stay in registers)
+                    uint32_t const last = units - 1;
+                    uint32_t const i0 = min(gl, last), i1 = min(gl + 16, last), i2 = min(gl + 32, last), i3 = min(gl + 48, last);
+                    uint4 const x0 = dc[i0], x1 = dc[i1], x2 = dc[i2], x3 = dc[i3];
+                    to[i0] = x0; to[i1] = x1; to[i2] = x2; to[i3] = x3;
+                    if (units > 64) {
+                        uint32_t const i4 = min(gl + 64, last), i5 = min(gl + 80, last), i6 = min(gl + 96, last), i7 = min(gl + 112, last);
+                        uint4 const x4 = dc[i4], x5 = dc[i5], x6 = dc[i6], x7 = dc[i7];
+                        to[i4] = x4; to[i5] = x5; to[i6] = x6; to[i7] = x7;
+                    }
                 }
                 logsPacked |= lg << (t == T_LL ? 0 : t == T_OF ? 8 : 16);
                 lds_sync();      // the note and the scratch are free again
@@ -3463,7 +3485,7 @@ __global__ __launch_bounds__(64 * kWf) __attribute__((amdgpu_waves_per_eu(4))) v
             if (pos > room || rest > room - pos) { ferr = E_dstSize_tooSmall; break; }
             uint8_t* const d = bdst + pos;
             if (litRle) { uint8_t const v = litBase[0]; for (uint32_t i = tid; i < rest; i += 64 * kWf) d[i] = v; }
-            else for (uint32_t i = tid; i < rest; i += 64 * kWf) d[i] = litBase[litPos + i];
+            else for (uint32_t i = tid; i < rest; i += 64 * kWf) d[i] = litBase[litPos + i];       // (byte-wise on purpose: the blocks this kernel takes end in few literals, and the wide copy costs registers)
             produced += pos + rest;
         }
     }

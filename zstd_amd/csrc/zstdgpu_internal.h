@@ -96,6 +96,9 @@ struct DevDict {
     uint16_t huf[kHufCells];   // {byte, nbBits<<8}
     uint32_t ll[512], of[256], ml[512];   // packed sequence cells
 };
+// (the kernels copy these tables 16 bytes at a time)
+static_assert(offsetof(DevDict, huf) % 16 == 0 && offsetof(DevDict, ll) % 16 == 0 && offsetof(DevDict, of) % 16 == 0 && offsetof(DevDict, ml) % 16 == 0,
+              "dictionary tables are 16-byte aligned");
 
 struct BatchParams {
     const uint8_t* src;          // device source buffer
