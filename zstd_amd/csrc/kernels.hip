@@ -3105,8 +3105,7 @@ __global__ __launch_bounds__(64 * kWf) __attribute__((amdgpu_waves_per_eu(4))) v
 #ifdef ZG_STAMPS
             uint64_t const y0 = __builtin_readcyclecounter();
             uint64_t y1 = y0, y2 = y0, y3 = y0, y4 = y0, y5 = y0;
-            uint32_t nLate = 0, nSlow = 0, nFarLate = 0, nHops = 0, wentSlow = 0;
-            uint32_t const slowTotal = 0;
+            uint32_t nLate = 0, nSlow = 0, nFarLate = 0, wentSlow = 0;
             uint64_t z1 = y0, z2 = y0, z3 = y0, z4 = y0, z5 = y0, z6 = y0;
 #endif
             announce();
@@ -3461,9 +3460,8 @@ __global__ __launch_bounds__(64 * kWf) __attribute__((amdgpu_waves_per_eu(4))) v
             if (p.dbg && lane == 0) {
                 unsigned long long* const g = (unsigned long long*)(p.dbg + 32 * (size_t)p.nBlocks + 32 * fi);
                 atomicAdd(g + 0, y2 - y0); atomicAdd(g + 1, y3 - y2); atomicAdd(g + 2, y4 - y3); atomicAdd(g + 3, y5 - y4);
-                atomicAdd(g + 4, (unsigned long long)nHops); atomicAdd(g + 5, (unsigned long long)wentSlow);
+                atomicAdd(g + 5, (unsigned long long)wentSlow);
                 atomicAdd(g + 6, 1ull); atomicAdd(g + 7, (unsigned long long)nLate); atomicAdd(g + 8, (unsigned long long)nSlow); atomicAdd(g + 9, (unsigned long long)nFarLate);
-                atomicAdd(g + 13, (unsigned long long)slowTotal);
                 atomicAdd(g + 22, z1 - y0); atomicAdd(g + 23, z2 - z1); atomicAdd(g + 24, z3 - z2); atomicAdd(g + 25, z4 - z3); atomicAdd(g + 26, z5 - z4); atomicAdd(g + 27, z6 - z5); atomicAdd(g + 28, y2 - z6);
             }
 #endif

@@ -861,11 +861,11 @@ extern "C" size_t zstdgpu_batch_decode(zstdgpu_batch* B, const void* devSrc, voi
             for (size_t i = 0; i < p.nBlocks; i++) { const uint64_t* q = h.data() + 8 * p.nBlocks + 8 * i; if (q[4] && q[4] * 100 >= big * 99) { for (int j = 0; j < 8; j++) u[j] += q[j]; m++; } }
             if (m) fprintf(stderr, "[stamps] k_sequences, %zu longest blocks (%.0f sequences): setup %.0f (descriptions staged at %.0f, tables built at %.0f, of which descriptions parsed by one lane %.0f)  in chain loop %.0f  whole kernel %.0f ticks; %.0f rounds\n", m, u[4] / m, u[0] / m, u[5] / m, u[6] / m, u[7] / m, u[1] / m, u[2] / m, u[3] / m);
         }
-        if (getenv("ZSTDGPU_EXECUTE") && !strcmp(getenv("ZSTDGPU_EXECUTE"), "four")) {
+        if (getenv("ZSTDGPU_EXECUTE") && (!strcmp(getenv("ZSTDGPU_EXECUTE"), "four") || !strcmp(getenv("ZSTDGPU_EXECUTE"), "eight"))) {
             double t[32] = {0}; size_t n = 0;
             for (size_t i = 0; i < p.nFrames; i++) if (h[32 * p.nBlocks + 32 * i + 6]) { for (int j = 0; j < 32; j++) t[j] += h[32 * p.nBlocks + 32 * i + j]; n++; }
-            if (n) fprintf(stderr, "[stamps] k_execute_wf per frame (summed over its waves): plan + early part %.0f  wait for turn %.0f  late part %.0f  flush %.0f ticks; %.0f batches (%.0f the slow way), late ring matches %.0f, dependent matches %.0f (%.0f bytes, %.0f trace rounds), late memory matches %.0f; memory-to-memory batches %.0f (plan + wait %.0f, copy %.0f ticks); from one batch complete to the next %.0f ticks, of which until the next wave notices %.0f; slow way because: dependent bytes > 64: %.1f, late memory match: %.1f, trace unfinished: %.1f, origin out of reach: %.1f, late ring bytes > 256: %.1f, floor moved: %.1f; early part = announce %.0f + plan %.0f + ring space, control words, load issue %.0f + trace %.0f + list %.0f + stage and runs %.0f + long runs %.0f\n",
-                           t[0] / n, t[1] / n, t[2] / n, t[3] / n, t[6] / n, t[5] / n, t[7] / n, t[8] / n, t[13] / n, t[4] / n, t[9] / n, t[10] / n, t[11] / n, t[12] / n, t[14] / n, t[15] / n, t[16] / n, t[17] / n, t[18] / n, t[19] / n, t[20] / n, t[21] / n, t[22] / n, t[23] / n, t[24] / n, t[25] / n, t[26] / n, t[27] / n, t[28] / n);
+            if (n) fprintf(stderr, "[stamps] k_execute_wf per frame (summed over its waves): plan + early part %.0f  wait for turn %.0f  late part %.0f  flush %.0f ticks; %.0f batches (%.0f the slow way), late ring matches %.0f, dependent matches %.0f, late memory matches %.0f; memory-to-memory batches %.0f (plan + wait %.0f, copy %.0f ticks); from one batch complete to the next %.0f ticks, of which until the next wave notices %.0f; slow way because: late memory match: %.1f, dependent match out of the ring's reach or over 64 bytes: %.1f, floor moved: %.1f; early part = records %.0f + plan %.0f + ring space, control words, load issue %.0f + dependent rounds %.0f + late bytes dealt out %.0f + stage and runs %.0f + long runs %.0f\n",
+                           t[0] / n, t[1] / n, t[2] / n, t[3] / n, t[6] / n, t[5] / n, t[7] / n, t[8] / n, t[9] / n, t[10] / n, t[11] / n, t[12] / n, t[14] / n, t[15] / n, t[17] / n, t[18] / n, t[21] / n, t[22] / n, t[23] / n, t[24] / n, t[25] / n, t[26] / n, t[27] / n, t[28] / n);
         } else {
         double t[8] = {0}; size_t n = 0;
         for (size_t i = 0; i < p.nFrames; i++) if (h[8 * i + 5]) { for (int j = 0; j < 8; j++) t[j] += h[8 * i + j]; n++; }
