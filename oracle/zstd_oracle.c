@@ -1194,6 +1194,11 @@ static U32 ZSTD_getLongOffsetsShare(const SeqTable* offTable)
 static int g_bodyPolicy = 0;
 void oracle_set_body(int policy) { g_bodyPolicy = policy; }
 
+/* Observer of every block's sequence section (the three tables in use, the bitstream, the count), called before the
+ * block's sequences are decoded: for study tools that include this file (tools/seq_sync_probe.c); it changes nothing. */
+typedef void (*oracle_seq_observer)(const SeqTable* ll, const SeqTable* of, const SeqTable* ml, const BYTE* stream, size_t streamSize, int nbSeq);
+static oracle_seq_observer g_seqObserver = 0;
+
 /* zstd_decompress_block.pas:1491-1542 */
 static size_t ZSTD_decompressBlock_internal(DCtx* dctx, BYTE* dst, size_t dstCapacity, const BYTE* src, size_t srcSize)
 {
@@ -1209,7 +1214,8 @@ static size_t ZSTD_decompressBlock_internal(DCtx* dctx, BYTE* dst, size_t dstCap
         size_t r;
         if (isErr(seqHSize)) return seqHSize;
         ip += seqHSize; srcSize -= seqHSize;
-        {   int usePrefetchDecoder = 0;      /* (ddictIsCold concerns digested dictionaries only: not on this path) */
+        if (g_seqObserver && nbSeq) g_seqObserver(dctx->LLTptr, dctx->OFTptr, dctx->MLTptr, ip, srcSize, nbSeq);
+        {   int usePrefetchDecoder = 0;     /* (ddictIsCold concerns digested dictionaries only: not on this path) */
             if (g_bodyPolicy == 1) usePrefetchDecoder = 1;
             else if (g_bodyPolicy == 0 && dctx->windowSize > (1ULL << 24) && nbSeq > ADVANCED_SEQS)
                 usePrefetchDecoder = ZSTD_getLongOffsetsShare(dctx->OFTptr) >= 7;
