@@ -379,7 +379,7 @@ def main():
     launch_cd = (c_bytes + d_bytes) / replicas            # algorithmic bytes of ONE launch on this rank
     achieved = launch_cd / (dom_ms * 1e-3) / 1e9
     dom_name = api.lib().zstdgpu_stage_kernel_name(dom).decode()
-    if dom_name == "k_execute" and n <= 1024 and not os.environ.get("ZSTDGPU_EXECUTE"):
+    if dom_name == "k_execute" and n <= 1024:
         dom_name = "k_execute_wf"     # (batches of up to 1024 frames of many sequences: the eight-wave kernel)
     # HBM bytes per launch of that kernel from the rocprofv3 PMC passes -- only when the committed summary was taken on this
     # configuration from these very kernel sources; a profile of other code says nothing about this run

@@ -275,6 +275,12 @@ size_t zstdgpu_batch_blockInfo(zstdgpu_batch* batch, uint32_t blockIdx,
                                uint32_t* litSize, uint32_t* nbSeq, uint64_t* regenSize, uint32_t* errorCode);
 size_t zstdgpu_batch_copyLiterals(zstdgpu_batch* batch, const void* devSrc, uint32_t blockIdx, void* out, size_t outCapacity);
 size_t zstdgpu_batch_copySequences(zstdgpu_batch* batch, uint32_t blockIdx, uint32_t* triples, size_t tripleCapacity);
+/* Which of the two execute kernels takes the frames of every later launch of this context (batches and the
+ * no-allocation entry point): 0 the library chooses by the shape of the batch (the default), 1 one wave per frame,
+ * 2 eight waves per frame.  Both kernels reproduce ZSTD_execSequence (decompress/zstd_decompress_block.pas:896-1039)
+ * and give the same bytes and verdicts; the knob exists so that tests and measurements can drive each of them over
+ * the same input.  Returns 0, or parameter_outOfBound. */
+size_t zstdgpu_test_setExecuteKernel(zstdgpu_ctx* ctx, int kernel);
 
 #ifdef __cplusplus
 }

@@ -41,11 +41,13 @@ def _noalloc(dctx, src, fin, dst_bytes, ddict=None):
     import gc
     gc.collect()        # (what the collector frees during the call would show as a change too)
     torch.cuda.synchronize()
-    before = torch.cuda.memory_allocated()
+    # free bytes of the device (hipMemGetInfo) see the library's own hipMalloc, which torch's allocator counters do not
+    before, free_before = torch.cuda.memory_allocated(), torch.cuda.mem_get_info()[0]
     api.decode_frames_noalloc(dctx, d_src.data_ptr(), src.nbytes, d_fin.data_ptr(), len(fin), d_dst.data_ptr(), d_st.data_ptr(),
                               ddict, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     assert torch.cuda.memory_allocated() == before
+    assert torch.cuda.mem_get_info()[0] == free_before
     st = d_st.cpu().numpy().view(api.FRAME_STATUS_DTYPE)[: len(fin)].copy()
     return st, d_dst.cpu().numpy()
 
@@ -94,6 +96,34 @@ def test_noalloc_with_dictionary(dctx):
     entries = [e for e in FRAMES if e.get("dict") == "dict16k"]
     _compare(dctx, entries, dd)
     dd.close()
+
+
+def test_noalloc_under_stream_capture(dctx):
+    """The advertised use: the call is recorded into a HIP graph (where an allocation is an error that ends the
+    capture) and the graph replayed twice into a destination refilled in between; verdicts and bytes as the batch path's."""
+    import torch
+    entries = [e for e in _entries(lambda e: e["capacity"] <= (1 << 16))][:40]
+    assert len(entries) >= 20
+    frames = [read_frame(e) for e in entries]
+    src, fin, dst_bytes = api.pack_frames(frames, [e["capacity"] for e in entries])
+    want_st, want_out = _reference(dctx, src, fin, dst_bytes)
+    d_src = torch.from_numpy(src).cuda()
+    d_fin = torch.from_numpy(fin.view(np.uint8).copy()).cuda()
+    d_dst = torch.full((dst_bytes,), 0x5A, dtype=torch.uint8, device="cuda")
+    d_st = torch.full((len(fin) * api.FRAME_STATUS_DTYPE.itemsize,), 0xEE, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):       # (capture mode "global": any allocating HIP call on any thread fails the capture)
+        api.decode_frames_noalloc(dctx, d_src.data_ptr(), src.nbytes, d_fin.data_ptr(), len(fin), d_dst.data_ptr(), d_st.data_ptr(),
+                                  None, torch.cuda.current_stream().cuda_stream)
+    for _ in range(2):
+        d_dst.fill_(0x5A)
+        d_st.fill_(0xEE)
+        g.replay()
+        torch.cuda.synchronize()
+        st = d_st.cpu().numpy().view(api.FRAME_STATUS_DTYPE)[: len(fin)]
+        assert np.array_equal(st, want_st)
+        assert np.array_equal(d_dst.cpu().numpy(), want_out)
 
 
 def test_noalloc_limits(dctx):

@@ -72,6 +72,7 @@ EXPORTS = (
     "zstdgpu_batch_scratchBytes", "zstdgpu_batch_set_profiling", "zstdgpu_batch_stage_ms", "zstdgpu_stage_kernel_name",
     "zstdgpu_decode_frames_noalloc",
     "zstdgpu_xxh64Batch", "zstdgpu_predefinedTables", "zstdgpu_batch_blockInfo", "zstdgpu_batch_copyLiterals", "zstdgpu_batch_copySequences",
+    "zstdgpu_test_setExecuteKernel",
 )
 
 
@@ -162,6 +163,7 @@ def lib():
     proto("zstdgpu_batch_blockInfo", sz, vp, u32, P(u32), P(u32), P(u64), P(u32))
     proto("zstdgpu_batch_copyLiterals", sz, vp, vp, u32, vp, sz)
     proto("zstdgpu_batch_copySequences", sz, vp, u32, vp, sz)
+    proto("zstdgpu_test_setExecuteKernel", sz, vp, ci)
     _lib = L
     return L
 
@@ -249,6 +251,13 @@ class DCtx:
 
     def reset(self, directive: int = ZSTD_reset_session_and_parameters):
         _check(lib().zstdgpu_DCtx_reset(self.h, directive))
+
+    EXECUTE_KERNELS = {"auto": 0, "one": 1, "eight": 2}
+
+    def set_execute_kernel(self, kernel: str):
+        """Tests and measurements: send every frame of later launches to one of the two execute kernels
+        ("one" wave per frame, "eight" waves per frame), or leave the choice to the library ("auto")."""
+        _check(lib().zstdgpu_test_setExecuteKernel(self.h, self.EXECUTE_KERNELS[kernel]))
 
     def close(self):
         if self.h:

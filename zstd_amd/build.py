@@ -19,7 +19,7 @@ def build_gpu(force=False):
     srcs = [os.path.join(CSRC, f) for f in ("zstdgpu_host.cpp", "kernels.hip", "descriptors.hip", "noalloc.hip")]
     deps = srcs + [os.path.join(CSRC, "zstdgpu_internal.h"), os.path.join(CSRC, "zstdgpu_objects.h"), os.path.join(ROOT, "include", "zstdgpu.h")]
     if force or _stale(out, deps):
-        subprocess.check_call(["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-Wall",
+        subprocess.check_call(["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-Wall", "-Wshadow",
                                "-Wno-unused-value", "-o", out] + srcs)
     return out
 

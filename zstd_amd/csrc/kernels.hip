@@ -659,8 +659,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
             for (uint32_t u = sl; u < units; u += 4 * kHufLanes) {
                 uint32_t const u1 = u + kHufLanes < units ? u + kHufLanes : u, u2 = u + 2 * kHufLanes < units ? u + 2 * kHufLanes : u,
                                u3 = u + 3 * kHufLanes < units ? u + 3 * kHufLanes : u;
-                uint4 const x0 = from[u], x1 = from[u1], x2 = from[u2], x3 = from[u3];
-                to[u] = x0; to[u1] = x1; to[u2] = x2; to[u3] = x3;
+                uint4 const q0 = from[u], q1 = from[u1], q2 = from[u2], q3 = from[u3];
+                to[u] = q0; to[u1] = q1; to[u2] = q2; to[u3] = q3;
             }
         } else {
             for (uint32_t n = sl; n < nbSymbols; n += kHufLanes) {
@@ -853,7 +853,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
                 if (!stage) {
 #pragma unroll
                     for (uint32_t i = 0; i < 12; i++) {
-                        uint32_t const g = 16 * i + sl, X = (g * 171u) >> 10, u = g - 6 * X;      // unit u of chain X (g / 6 for g < 192)
+                        uint32_t const gi = 16 * i + sl, X = (gi * 171u) >> 10, u = gi - 6 * X;      // unit u of chain X (gi / 6 for gi < 192)
                         if ((pvMask >> i) & 1) *(uint4*)(winAll + X * kSpecWinDw + 4 * u) = pvT[i];
                     }
                 }
@@ -871,7 +871,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
                 lds_sync();
 #pragma unroll
                 for (uint32_t i = 0; i < 12; i++) {
-                    uint32_t const g = 16 * i + sl, X = (g * 171u) >> 10, u = g - 6 * X;
+                    uint32_t const gi = 16 * i + sl, X = (gi * 171u) >> 10, u = gi - 6 * X;
                     uint64_t const base = reqAll[X];
                     pvT[i] = ld_unit_any(base ? (uintptr_t)base + 16 * u : floorAddr, floorAddr);       // (every lane loads: a fixed number of loads in flight)
                     pvMask |= base ? (1u << i) : 0u;
@@ -967,10 +967,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
                                 ckv[c] = (!last && q[c] < 16) ? (uint32_t)ckAll[16 * (k + 4 * (last ? 0u : t[c])) + (q[c] < 16 ? q[c] : 0u)] : 0xFFFFu;
                                 bool const valid = last || ckv[c] < 0xFFFEu;      // (0xFFFF: not noted yet, or no notes left)
                                 int const goal = last ? 0 : Bt[c] - (int)ckv[c];
-                                bool const x0 = valid && cb0 == goal, x1 = valid && cb1 == goal, x2 = valid && cb2 == goal, x3 = valid && cb3 == goal;
-                                if ((x0 | x1 | x2 | x3) && open0) {
+                                bool const m0 = valid && cb0 == goal, m1 = valid && cb1 == goal, m2 = valid && cb2 == goal, m3 = valid && cb3 == goal;
+                                if ((m0 | m1 | m2 | m3) && open0) {
                                     met[c] = true;
-                                    upTo[c] = nDec[c] + (x0 ? 0u : x1 ? 1u : x2 ? 2u : 3u);
+                                    upTo[c] = nDec[c] + (m0 ? 0u : m1 ? 1u : m2 ? 2u : 3u);
                                     hdT[c] = kSpecRound * q[c];
                                 }
                             }
@@ -1798,12 +1798,12 @@ __global__ __launch_bounds__(kSeqThreads) void k_sequences(BatchParams p)
                     // (a lane with no piece left in a pass copies the table's last piece again: the pieces stay in registers)
                     uint32_t const last = units - 1;
                     uint32_t const i0 = min(gl, last), i1 = min(gl + 16, last), i2 = min(gl + 32, last), i3 = min(gl + 48, last);
-                    uint4 const x0 = dc[i0], x1 = dc[i1], x2 = dc[i2], x3 = dc[i3];
-                    to[i0] = x0; to[i1] = x1; to[i2] = x2; to[i3] = x3;
+                    uint4 const q0 = dc[i0], q1 = dc[i1], q2 = dc[i2], q3 = dc[i3];
+                    to[i0] = q0; to[i1] = q1; to[i2] = q2; to[i3] = q3;
                     if (units > 64) {
                         uint32_t const i4 = min(gl + 64, last), i5 = min(gl + 80, last), i6 = min(gl + 96, last), i7 = min(gl + 112, last);
-                        uint4 const x4 = dc[i4], x5 = dc[i5], x6 = dc[i6], x7 = dc[i7];
-                        to[i4] = x4; to[i5] = x5; to[i6] = x6; to[i7] = x7;
+                        uint4 const q4 = dc[i4], q5 = dc[i5], q6 = dc[i6], q7 = dc[i7];
+                        to[i4] = q4; to[i5] = q5; to[i6] = q6; to[i7] = q7;
                     }
                 }
                 logsPacked |= lg << (t == T_LL ? 0 : t == T_OF ? 8 : 16);
@@ -1936,7 +1936,7 @@ __global__ __launch_bounds__(kSeqThreads) void k_sequences(BatchParams p)
                             asm volatile("" : "+v"(S));
                             S += quad_perm<0x4E>(S);                    // lanes 2 3 0 1
                             // state bits, order LL, ML, OF (:1220-1225): this lane's lie under those of the tables before it
-                            uint32_t const n = cell_nbBits(c);
+                            uint32_t const nb = cell_nbBits(c);
                             uint32_t const ng = __builtin_amdgcn_ubfe(c, 14, 5);
                             uint32_t const o = ng + (quad_perm<0x90>(ng) & mask1) + (quad_perm<0x40>(ng) & mask2);   // + the lane below, + two lanes below; mod 32
                             // the 32 bits under the additional bits: bit R = 63 - (their number) of (t2:t1:t0) upwards
@@ -1946,7 +1946,7 @@ __global__ __launch_bounds__(kSeqThreads) void k_sequences(BatchParams p)
                             uint32_t const t2 = __builtin_amdgcn_alignbit(a3, a2, T), t1 = __builtin_amdgcn_alignbit(a2, a1, T), t0 = __builtin_amdgcn_alignbit(a1, a0, T);
                             uint32_t const h3 = __builtin_amdgcn_alignbit(up ? t2 : t1, up ? t1 : t0, R);
                             // a cell's nextState has its low nbBits clear
-                            st = (c & 0x1FF) | __builtin_amdgcn_ubfe(h3, o, n);
+                            st = (c & 0x1FF) | __builtin_amdgcn_ubfe(h3, o, nb);
                             uint32_t const cn = *(lds_u32)(uintptr_t)(tabL + 4 * st);
                             __builtin_amdgcn_sched_barrier(0);
                             uint32_t const Tprev = T;
@@ -2107,15 +2107,15 @@ __global__ __launch_bounds__(kSeqThreads) void k_sequences(BatchParams p)
 #endif
     wave_sync();         // the round stores are complete before the end record goes on top of one of them
     if (helper && hasJob && gl == 0) {
-        DevBlockState* const st = p.state + b;
+        DevBlockState* const bs = p.state + b;
         if (failU) {
-            st->seqErr = E_corruption; st->seqValid = 0; st->tailErr = 0; st->regen = blk.litSize;
-            st->repOut[0] = kSlot0; st->repOut[1] = kSlot1; st->repOut[2] = kSlot2;
+            bs->seqErr = E_corruption; bs->seqValid = 0; bs->tailErr = 0; bs->regen = blk.litSize;
+            bs->repOut[0] = kSlot0; bs->repOut[1] = kSlot1; bs->repOut[2] = kSlot2;
             out[0] = make_uint4(0, 0, 0, 0);
         } else {
             out[nValid] = make_uint4(0, outPos, litPos, 0);      // end record
-            st->seqErr = 0;
-            st->seqValid = nValid;
+            bs->seqErr = 0;
+            bs->seqValid = nValid;
             // A stream that ran dry before the block's last sequence is not an error in the reference: its reads go on
             // answering from the last container (bitstream.pas:300-314).  Such blocks (damaged input only) are decoded
             // again, serially and to the letter, by k_sequences_dry.
@@ -2124,9 +2124,9 @@ __global__ __launch_bounds__(kSeqThreads) void k_sequences(BatchParams p)
             // the prefetching loop of 1.4.8 has no such check
             bool unfinished = nValid == nbSeq && (int)Qend > (int)Qstart;
             if (unfinished && prefetching_loop_148(p.frames[blk.frameIdx].longWindow, nbSeq, tOF, (ctl[slot].logs >> 8) & 255)) unfinished = false;
-            st->tailErr = unfinished ? (uint32_t)E_corruption : 0u;
-            st->regen = (uint64_t)outPos + (litPos <= blk.litSize ? blk.litSize - litPos : 0);
-            st->repOut[0] = rep.a; st->repOut[1] = rep.b; st->repOut[2] = rep.c;
+            bs->tailErr = unfinished ? (uint32_t)E_corruption : 0u;
+            bs->regen = (uint64_t)outPos + (litPos <= blk.litSize ? blk.litSize - litPos : 0);
+            bs->repOut[0] = rep.a; bs->repOut[1] = rep.b; bs->repOut[2] = rep.c;
         }
     }
 }
@@ -2544,10 +2544,21 @@ DEVI bool frame_uses_wf(const BatchParams& p, const DevFrame& f)
     return nb != 0 && seqs >= 1024ull * nb;
 }
 
-constexpr uint32_t kOutStage = 4096;     // output bytes of one batch assembled in LDS
-constexpr uint32_t kOutHist = 7168;      // the output stage: a batch and the output of the batches before it
+// (the three sizes can be set from the compiler command line for experiments: how the stage's time depends on its LDS)
+#ifndef ZG_OUT_STAGE
+#define ZG_OUT_STAGE 4096
+#endif
+#ifndef ZG_OUT_HIST
+#define ZG_OUT_HIST 7168
+#endif
+#ifndef ZG_LIT_STAGE
+#define ZG_LIT_STAGE 1024
+#endif
+constexpr uint32_t kOutStage = ZG_OUT_STAGE;     // output bytes of one batch assembled in LDS
+constexpr uint32_t kOutHist = ZG_OUT_HIST;       // the output stage: a batch and the output of the batches before it
 constexpr uint32_t kOutKeep = kOutHist - kOutStage;     // history kept when the stage is full (its tail moves to the front)
-constexpr uint32_t kLitStage = 1024;     // literal bytes of one batch staged in LDS
+constexpr uint32_t kLitStage = ZG_LIT_STAGE;     // literal bytes of one batch staged in LDS
+static_assert(kOutStage <= kOutHist && kOutStage % 16 == 0 && kOutHist % 16 == 0 && kLitStage % 16 == 0 && kLitStage <= 1024, "stage sizes");
 
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_execute(BatchParams p)
 {
@@ -2785,7 +2796,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
                         __builtin_memcpy(outStage + o, &x, 16);
                     }
                 }
-                if (litRle) *(uint4*)(litStage + 16 * lane) = make_uint4(rleFill, rleFill, rleFill, rleFill);
+                if (litRle) { if (16 * lane < kLitStage) *(uint4*)(litStage + 16 * lane) = make_uint4(rleFill, rleFill, rleFill, rleFill); }
                 else {
                     if (lane < litFull) *(uint4*)(litStage + 16 * lane) = litV;
                     if (lane < litTail) litStage[16 * litFull + lane] = litT;
@@ -2989,13 +3000,14 @@ struct WfLateStep {
 };
 
 // Polls LDS control words until `cond`; what follows is not moved above it.  The wait is bounded (far beyond what a
-// block can take): should the protocol ever stall, the frame ends with an error instead of a wave that never finishes.
+// block can take): should the protocol ever stall, the frame ends with an error instead of a wave that never finishes
+// (a verdict already written -- a real error of the frame that made the others stop -- is kept).
 #define WF_SPIN(cond)                                                                                   \
     do {                                                                                                \
         uint32_t spins_ = 0;                                                                            \
         while (!(cond)) {                                                                               \
             __builtin_amdgcn_s_sleep(kWfNap);                                                           \
-            if (++spins_ > (1u << 22)) { ctl[WF_ERR] = E_generic; ctl[WF_DONE] = kWfAbort; stalled = true; break; } \
+            if (++spins_ > (1u << 22)) { if (!ctl[WF_ERR]) ctl[WF_ERR] = E_generic; ctl[WF_DONE] = kWfAbort; stalled = true; break; } \
         }                                                                                               \
         asm volatile("" ::: "memory");                                                                  \
     } while (0)
@@ -3656,20 +3668,15 @@ void launch_layout(const BatchParams& p, void* stream)
     if (!p.nFrames) return;
     hipLaunchKernelGGL(k_layout, dim3((p.nFrames + 63) / 64), dim3(64), 0, (hipStream_t)stream, p);
 }
-// ZSTDGPU_EXECUTE=one|four in the environment sends every frame to one of the two execute kernels (tests, measurements);
-// looked up at every launch, so a test can switch between them
-static uint32_t exec_mode_env()
-{
-    const char* const e = getenv("ZSTDGPU_EXECUTE");
-    return !e ? 0u : !strcmp(e, "one") ? 1u : !strcmp(e, "four") || !strcmp(e, "eight") ? 2u : 0u;
-}
+// pIn.execMode: 1 or 2 sends every frame to one of the two execute kernels (zstdgpu_test_setExecuteKernel: tests,
+// measurements); 0 leaves the choice to the shape of the batch and of each frame
 void launch_execute(const BatchParams& pIn, void* stream)
 {
     if (!pIn.nFrames) return;
     BatchParams p = pIn;
     // Eight waves per frame pay off while the chip has room for them: two such workgroups fit a compute unit, and past
     // four rounds of them one wave per frame (all frames resident at once) is the faster kernel.
-    uint32_t const forced = exec_mode_env();
+    uint32_t const forced = pIn.execMode <= 2 ? pIn.execMode : 0u;
     p.execMode = forced ? forced : (p.nFrames > kWfMaxFrames ? 1u : 0u);
     if (p.execMode != 1) hipLaunchKernelGGL(k_execute_wf, dim3(p.nFrames), dim3(64 * kWf), 0, (hipStream_t)stream, p);
     if (p.execMode != 2) hipLaunchKernelGGL(k_execute, dim3(p.nFrames), dim3(64), 0, (hipStream_t)stream, p);

@@ -128,6 +128,7 @@ extern "C" size_t zstdgpu_decode_frames_noalloc(zstdgpu_ctx* ctx, const void* de
     p.litJobs = litJobs; p.seqJobs = seqJobs; p.dryList = (uint32_t*)(ptr + oDryList);
     p.nLitJobs = kMaxBlocks; p.nSeqJobs = kMaxBlocks; p.nFrames = nFrames; p.nBlocks = kMaxBlocks;
     p.devTotals = totals;
+    p.execMode = ctx->execKernel;
     if (ddict) {
         p.dict = ddict->dDict;
         p.dictContent = ddict->dBytes + ddict->entropySize;

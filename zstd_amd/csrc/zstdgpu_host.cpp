@@ -180,6 +180,9 @@ struct zstdgpu_batch {
     // the literal pack kernel runs beside the sequence kernel on a stream of its own, forked and joined with events
     hipStream_t side = nullptr;
     hipEvent_t evFork = nullptr, evJoin = nullptr;
+    // recorded behind the last kernel of every decode: what the queries and the destructor wait for (a stream handle kept
+    // from the last launch may be gone by then), and what a decode on another stream waits for before it reuses the scratch
+    hipEvent_t evDone = nullptr;
 };
 
 namespace {
@@ -284,6 +287,16 @@ void parse_sections(const uint8_t* payload, DevBlock& d)
 
 bool set_device(const zstdgpu_batch* b) { return hipSetDevice(b->device) == hipSuccess; }
 
+// Every launch of the batch so far is over (launches on different streams are chained through evDone, so the last one
+// covers them all).  An event that cannot be waited for (recorded under stream capture) falls back to the whole device.
+bool wait_done(const zstdgpu_batch* b)
+{
+    if (!b->launched) return true;
+    if (b->evDone && hipEventSynchronize(b->evDone) == hipSuccess) return true;
+    (void)hipGetLastError();
+    return hipDeviceSynchronize() == hipSuccess;
+}
+
 // A batch is known to its context so that a context destroyed first can tell it (zstdgpu_destroy).
 bool adopt_batch(zstdgpu_ctx* ctx, zstdgpu_batch* b)
 {
@@ -305,7 +318,8 @@ void free_batch_device(zstdgpu_batch* b)
     // zstdgpu_batch_decode is asynchronous and nothing obliges the caller to wait before destroying the batch: the
     // big buffers go back to the context's spare list (no implicit synchronisation as with hipFree), where the next
     // batch may pick them up and launch on another stream -- so the last launch must be over first.
-    if (b->launched) { hipStreamSynchronize(b->lastStream); if (b->side) hipStreamSynchronize(b->side); }
+    wait_done(b);
+    if (b->launched && b->side) hipStreamSynchronize(b->side);
     hipFree(b->dBlocks); hipFree(b->dState); hipFree(b->dFrames); hipFree(b->dStatus);
     bfree(b->ctx, b->dLitBuf, b->litBufBytes); bfree(b->ctx, b->dLitTmp, b->litTmpBytes); bfree(b->ctx, b->dSeqBuf, b->seqBufBytes);
     hipFree(b->dLitJobs); hipFree(b->dSeqJobs); hipFree(b->dPackTab); hipFree(b->dDryList);
@@ -313,6 +327,7 @@ void free_batch_device(zstdgpu_batch* b)
     if (b->side) hipStreamDestroy(b->side);
     if (b->evFork) hipEventDestroy(b->evFork);
     if (b->evJoin) hipEventDestroy(b->evJoin);
+    if (b->evDone) hipEventDestroy(b->evDone);
 }
 
 }  // namespace
@@ -685,7 +700,8 @@ extern "C" zstdgpu_batch* zstdgpu_batch_create(zstdgpu_ctx* ctx, const void* hos
     ok = ok && up(B->dBlocks, B->hBlocks.data(), nBlocks * sizeof(DevBlock)) && up(B->dFrames, B->hFrames.data(), nFrames * sizeof(DevFrame)) &&
          up(B->dLitJobs, B->hLitJobs.data(), B->hLitJobs.size() * 4) && up(B->dSeqJobs, B->hSeqJobs.data(), B->hSeqJobs.size() * 4);
     ok = ok && hipStreamCreateWithFlags(&B->side, hipStreamNonBlocking) == hipSuccess &&
-         hipEventCreateWithFlags(&B->evFork, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&B->evJoin, hipEventDisableTiming) == hipSuccess;
+         hipEventCreateWithFlags(&B->evFork, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&B->evJoin, hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&B->evDone, hipEventDisableTiming) == hipSuccess;
     if (!ok) { free_batch_device(B); drop_batch(B); return nullptr; }
     return B;
 }
@@ -751,7 +767,8 @@ extern "C" zstdgpu_batch* zstdgpu_batch_create_on_device(zstdgpu_ctx* ctx, const
         B->mirrored = false;
     }
     ok = ok && hipStreamCreateWithFlags(&B->side, hipStreamNonBlocking) == hipSuccess &&
-         hipEventCreateWithFlags(&B->evFork, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&B->evJoin, hipEventDisableTiming) == hipSuccess;
+         hipEventCreateWithFlags(&B->evFork, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&B->evJoin, hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&B->evDone, hipEventDisableTiming) == hipSuccess;
     cleanup();
     if (!ok) { free_batch_device(B); drop_batch(B); return nullptr; }
     return B;
@@ -804,6 +821,7 @@ extern "C" size_t zstdgpu_batch_decode(zstdgpu_batch* B, const void* devSrc, voi
     p.litBuf = B->dLitBuf; p.litTmp = B->dLitTmp; p.packTab = B->dPackTab; p.seqBuf = B->dSeqBuf; p.litJobs = B->dLitJobs; p.seqJobs = B->dSeqJobs; p.dryList = B->dDryList;
     p.nLitJobs = B->nLitJobs; p.nSeqJobs = B->nSeqJobs;
     p.nFrames = B->nFrames; p.nBlocks = B->nBlocks;
+    p.execMode = B->ctx ? B->ctx->execKernel : 0u;
     if (B->ddict) {
         p.dict = B->ddict->dDict;
         p.dictContent = B->ddict->dBytes + B->ddict->entropySize;
@@ -815,6 +833,8 @@ extern "C" size_t zstdgpu_batch_decode(zstdgpu_batch* B, const void* devSrc, voi
     hipMemsetAsync(dbgBuf, 0, (size_t)p.nBlocks * 512, s);
     p.dbg = dbgBuf;
 #endif
+    // the scratch of the batch is shared by its launches: one on another stream than the last waits for that one
+    if (B->launched && s != B->lastStream) hipStreamWaitEvent(s, B->evDone, 0);
     bool const prof = B->profiling && B->evReady;
     if (prof) hipEventRecord(B->ev[0], s);
     if (p.nBlocks) hipMemsetAsync(B->dState, 0, (size_t)p.nBlocks * sizeof(DevBlockState), s);
@@ -836,6 +856,7 @@ extern "C" size_t zstdgpu_batch_decode(zstdgpu_batch* B, const void* devSrc, voi
     if (prof) hipEventRecord(B->ev[4], s);
     launch_checksum(p, s);
     if (prof) { hipEventRecord(B->ev[5], s); B->evRecorded = true; }
+    hipEventRecord(B->evDone, s);
     B->lastStream = s; B->launched = true;
 #ifdef ZG_STAMPS
     {   // diagnostic build: print where the sequence stage spends its cycles
@@ -861,7 +882,7 @@ extern "C" size_t zstdgpu_batch_decode(zstdgpu_batch* B, const void* devSrc, voi
             for (size_t i = 0; i < p.nBlocks; i++) { const uint64_t* q = h.data() + 8 * p.nBlocks + 8 * i; if (q[4] && q[4] * 100 >= big * 99) { for (int j = 0; j < 8; j++) u[j] += q[j]; m++; } }
             if (m) fprintf(stderr, "[stamps] k_sequences, %zu longest blocks (%.0f sequences): setup %.0f (descriptions staged at %.0f, tables built at %.0f, of which descriptions parsed by one lane %.0f)  in chain loop %.0f  whole kernel %.0f ticks; %.0f rounds\n", m, u[4] / m, u[0] / m, u[5] / m, u[6] / m, u[7] / m, u[1] / m, u[2] / m, u[3] / m);
         }
-        if (getenv("ZSTDGPU_EXECUTE") && (!strcmp(getenv("ZSTDGPU_EXECUTE"), "four") || !strcmp(getenv("ZSTDGPU_EXECUTE"), "eight"))) {
+        if (p.execMode == 2) {
             double t[32] = {0}; size_t n = 0;
             for (size_t i = 0; i < p.nFrames; i++) if (h[32 * p.nBlocks + 32 * i + 6]) { for (int j = 0; j < 32; j++) t[j] += h[32 * p.nBlocks + 32 * i + j]; n++; }
             if (n) fprintf(stderr, "[stamps] k_execute_wf per frame (summed over its waves): plan + early part %.0f  wait for turn %.0f  late part %.0f  flush %.0f ticks; %.0f batches (%.0f the slow way), late ring matches %.0f, dependent matches %.0f, late memory matches %.0f; memory-to-memory batches %.0f (plan + wait %.0f, copy %.0f ticks); from one batch complete to the next %.0f ticks, of which until the next wave notices %.0f; slow way because: late memory match: %.1f, dependent match out of the ring's reach or over 64 bytes: %.1f, floor moved: %.1f; early part = records %.0f + plan %.0f + ring space, control words, load issue %.0f + dependent rounds %.0f + late bytes dealt out %.0f + stage and runs %.0f + long runs %.0f\n",
@@ -880,7 +901,7 @@ extern "C" size_t zstdgpu_batch_decode(zstdgpu_batch* B, const void* devSrc, voi
 extern "C" size_t zstdgpu_batch_status(zstdgpu_batch* B, zstdgpu_frame_status* status)
 {
     if (!B || !set_device(B)) return mkerr(E_generic);
-    if (hipStreamSynchronize(B->lastStream) != hipSuccess) return mkerr(E_generic);
+    if (!wait_done(B)) return mkerr(E_generic);
     static_assert(sizeof(zstdgpu_frame_status) == sizeof(DevFrameStatus), "status layout");
     if (status && B->nFrames &&
         hipMemcpy(status, B->dStatus, (size_t)B->nFrames * sizeof(DevFrameStatus), hipMemcpyDeviceToHost) != hipSuccess)
@@ -951,7 +972,7 @@ extern "C" size_t zstdgpu_predefinedTables(zstdgpu_ctx* ctx, uint32_t* cells)
 extern "C" size_t zstdgpu_batch_blockInfo(zstdgpu_batch* B, uint32_t bi, uint32_t* litSize, uint32_t* nbSeq, uint64_t* regenSize, uint32_t* errorCode)
 {
     if (!B || bi >= B->nBlocks || !set_device(B) || !mirror(B)) return mkerr(E_generic);
-    if (hipStreamSynchronize(B->lastStream) != hipSuccess) return mkerr(E_generic);
+    if (!wait_done(B)) return mkerr(E_generic);
     DevBlockState st;
     if (hipMemcpy(&st, B->dState + bi, sizeof(st), hipMemcpyDeviceToHost) != hipSuccess) return mkerr(E_generic);
     const DevBlock& d = B->hBlocks[bi];
@@ -965,7 +986,7 @@ extern "C" size_t zstdgpu_batch_blockInfo(zstdgpu_batch* B, uint32_t bi, uint32_
 extern "C" size_t zstdgpu_batch_copyLiterals(zstdgpu_batch* B, const void* devSrc, uint32_t bi, void* out, size_t cap)
 {
     if (!B || bi >= B->nBlocks || !set_device(B) || !mirror(B)) return mkerr(E_generic);
-    if (hipStreamSynchronize(B->lastStream) != hipSuccess) return mkerr(E_generic);
+    if (!wait_done(B)) return mkerr(E_generic);
     const DevBlock& d = B->hBlocks[bi];
     if (d.blockType != BT_COMPRESSED || d.hostLitErr) return mkerr(E_generic);
     if (d.litSize > cap) return mkerr(E_dstSize_tooSmall);
@@ -985,7 +1006,7 @@ extern "C" size_t zstdgpu_batch_copyLiterals(zstdgpu_batch* B, const void* devSr
 extern "C" size_t zstdgpu_batch_copySequences(zstdgpu_batch* B, uint32_t bi, uint32_t* triples, size_t tripleCapacity)
 try {
     if (!B || bi >= B->nBlocks || !set_device(B) || !mirror(B)) return mkerr(E_generic);
-    if (hipStreamSynchronize(B->lastStream) != hipSuccess) return mkerr(E_generic);
+    if (!wait_done(B)) return mkerr(E_generic);
     const DevBlock& d = B->hBlocks[bi];
     if (d.blockType != BT_COMPRESSED || d.hostLitErr || d.hostSeqErr) return mkerr(E_generic);
     if (d.nbSeq > tripleCapacity) return mkerr(E_dstSize_tooSmall);
@@ -1235,6 +1256,14 @@ extern "C" size_t zstdgpu_DCtx_refDDict(zstdgpu_ctx* ctx, const zstdgpu_ddict* d
     if (!ctx) return mkerr(E_generic);
     if (any_stream_busy(ctx)) return mkerr(E_stage_wrong);
     ctx->refDDict = ddict;
+    return 0;
+}
+// which execute kernel takes the frames of later launches (tests and measurements; not a reference function)
+extern "C" size_t zstdgpu_test_setExecuteKernel(zstdgpu_ctx* ctx, int kernel)
+{
+    if (!ctx) return mkerr(E_generic);
+    if (kernel < 0 || kernel > 2) return mkerr(E_parameter_outOfBound);
+    ctx->execKernel = (uint32_t)kernel;
     return 0;
 }
 extern "C" size_t zstdgpu_DCtx_reset(zstdgpu_ctx* ctx, zstdgpu_ResetDirective reset)            // ZSTD_DCtx_reset :1809-1826

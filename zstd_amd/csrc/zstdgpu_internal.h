@@ -118,7 +118,8 @@ struct BatchParams {
     const uint8_t* dictContent;  // device pointer to dictionary content
     uint32_t dictContentSize;
     uint32_t nLitJobs, nSeqJobs, nFrames, nBlocks;
-    uint32_t execMode;           // which execute kernel takes a frame: 0 by its shape, 1 always one wave, 2 always four (set by launch_execute)
+    uint32_t execMode;           // which execute kernel takes a frame: 0 by its shape, 1 always one wave, 2 always eight (the caller's wish on
+                                 // entry to launch_execute, which settles the 0 case by the size of the batch)
     // When set, the block and job counts are read from these device totals (layout of the descriptor builder's
     // `totals`) instead of the fields above, which then only bound the grids: the descriptors were built on the
     // device and nothing came back to the host.  totals[7] != 0: the batch does not fit its scratch, nothing is decoded.

@@ -28,6 +28,7 @@ struct zstdgpu_ctx {
     std::vector<zstdgpu_ddict*> ddicts;           // dictionaries created on it (they forget it when it is destroyed)
     std::vector<zstdgpu_batch*> batches;          // batches created on it (likewise)
     uint8_t* scratch = nullptr;                   // this device's fixed scratch array (zstdgpu_decode_frames_noalloc)
+    uint32_t execKernel = 0;                      // zstdgpu_test_setExecuteKernel: 0 chosen per launch, 1 one wave per frame, 2 eight
     uint32_t opts() const { return (format ? zg::kOptMagicless : 0u) | (ignoreChecksum ? zg::kOptIgnoreChecksum : 0u); }
     void reset_parameters() { format = 0; maxWindowSize = (1ull << 27) + 1; stableOut = 0; ignoreChecksum = 0; }
 };
