@@ -215,11 +215,49 @@ def cpu_baseline(frames, caps, dictionary, budget_s: float = 20.0):
                      "sample": f"1 thread: first {sample1} frames x {reps1} passes, {dt1:.1f} s; {threads} threads over frames: all {len(frames)} frames x {repsN} passes, {dtN:.1f} s"}
     out = {"value": res["port"]["all_threads_GBps"], "unit": "GB/s", "cores": threads, "kind": "port",
            "sample": res["port"]["sample"], "one_thread_value": res["port"]["one_thread_GBps"], "cpu_model": cpu_model(),
+           "cores_of_the_box": os.cpu_count(), "cores_this_process_may_use": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
+           "cores_note": "`cores` = worker threads used: the CPUs this process may use, capped at 16 (the share of a one-GPU job on the test boxes)",
            "note": "the oracle is a plain C restatement of the reference's decoder, not a tuned one: the system libzstd (same algorithm, upstream's tuned C) is the figure a host would really get"}
     if "libzstd" in res:
         from zstd_amd import corpus as c2
         out["libzstd"] = dict(res["libzstd"], kind="libzstd", version=c2.SystemZstd().version, value=res["libzstd"]["all_threads_GBps"], cores=threads, unit="GB/s")
     return out
+
+
+def one_shot_latency(dctx, calls: int = 200):
+    """Per-call cost of the one-shot drop-ins on a small frame: a committed 4 KB record compressed with the committed 16 KB
+    dictionary, host buffers in and out.  `rebuilt`: zstdgpu_decompress_usingDDict as a caller of the reference's
+    ZSTD_decompress_usingDDict would use it (frame walk, a batch made and destroyed, two copies, every call).  `reused`:
+    the same frame as a batch prepared once, decoded on device buffers and its verdict read back, every call."""
+    import torch
+    from zstd_amd import api
+    gold = os.path.join(ROOT, "tests", "golden")
+    manifest = json.load(open(os.path.join(gold, "manifest.json")))
+    e = {x["name"]: x for x in manifest["frames"]}["rec00_dict"]
+    fr = open(os.path.join(gold, e["file"]), "rb").read()
+    dd = api.DDict(dctx, open(os.path.join(gold, manifest["dicts"]["dict16k"]["file"]), "rb").read())
+    want = api.ZSTD_decompress_usingDDict(dctx, fr, e["capacity"], dd)
+    assert len(want) == e["capacity"]
+    t0 = time.perf_counter()
+    for _ in range(calls):
+        api.ZSTD_decompress_usingDDict(dctx, fr, e["capacity"], dd)
+    rebuilt = (time.perf_counter() - t0) / calls
+    src, fin, dst_bytes = api.pack_frames([fr], [e["capacity"]])
+    d_src = torch.from_numpy(src).cuda()
+    d_dst = torch.zeros(dst_bytes, dtype=torch.uint8, device="cuda")
+    b = api.Batch(dctx, src, fin, dd)
+    stream = torch.cuda.current_stream().cuda_stream
+    b.decode(d_src.data_ptr(), d_dst.data_ptr(), stream)
+    assert int(b.status()[0]["errorCode"]) == 0 and d_dst.cpu().numpy().tobytes()[: len(want)] == want
+    t0 = time.perf_counter()
+    for _ in range(calls):
+        b.decode(d_src.data_ptr(), d_dst.data_ptr(), stream)
+        b.status()
+    reused = (time.perf_counter() - t0) / calls
+    b.close()
+    dd.close()
+    return {"frame": "tests/golden rec00_dict (4096 B record, 774 B compressed, 16 KB dictionary)", "calls": calls,
+            "decompress_usingDDict_us_per_call": round(rebuilt * 1e6, 1), "prepared_batch_decode_and_status_us_per_call": round(reused * 1e6, 1)}
 
 
 def spawn_ranks(args) -> int:
@@ -411,6 +449,8 @@ def main():
         "pcie_inclusive_GBps": round(e2e, 2) if e2e else None,
         "scratch_bytes": batch.scratch_bytes, "kernel_source_digest": digest,
     }
+    if world == 1:
+        out["one_shot_latency"] = one_shot_latency(dctx)
     if world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(frames, caps, w["dictionary"])
     print(json.dumps(out))
