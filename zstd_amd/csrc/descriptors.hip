@@ -319,7 +319,7 @@ void launch_scan_frames(const uint8_t* src, uint64_t srcBytes, const FrameIn* in
                         DevFrame* frames, uint32_t* slots, uint64_t* totals, void* stream, ScratchCaps caps)
 {
     if (nFrames) hipLaunchKernelGGL(k_scan_frames, dim3((nFrames + 63) / 64), dim3(64), 0, (hipStream_t)stream, src, srcBytes, in, nFrames, batchDictID, opts, frames, slots);
-    hipMemsetAsync(totals, 0, 8 * sizeof(uint64_t), (hipStream_t)stream);
+    launch_zero(totals, 8 * sizeof(uint64_t), stream);      // (a kernel: a memset node this small is not reliable in a replayed graph)
     hipLaunchKernelGGL(k_first_blocks, dim3(1), dim3(kScanThreads), 0, (hipStream_t)stream, slots, in, nFrames, frames, totals, caps.maxBlocks);
 }
 

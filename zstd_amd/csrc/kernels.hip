@@ -1592,7 +1592,12 @@ DEVI uint32_t quad_lane(uint32_t x) { return (uint32_t)__builtin_amdgcn_mov_dpp(
 // lane 15 - i of the row (row_mirror): the first lane of a row receives the last lane's value
 DEVI uint32_t row_last_to_first(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x140, 0xF, 0xF, false); }
 constexpr int kSeqJobs = 16;                // jobs (blocks) per workgroup
-constexpr int kSeqThreads = 64 * 5;         // wave 0: the serial chains, four lanes per job; waves 1-4: helpers, 16 lanes per job
+#ifndef ZG_CHAIN_WAVES
+#define ZG_CHAIN_WAVES 1
+#endif
+constexpr int kChainWaves = ZG_CHAIN_WAVES;  // 1: one wave runs the chains of all 16 jobs; 4: four waves, four jobs (16 lanes) each
+static_assert(kChainWaves == 1 || kChainWaves == 4, "chain waves");
+constexpr int kSeqThreads = 64 * (kChainWaves + 4);   // chain waves: the serial chains, four lanes per job; then four helper waves, 16 lanes per job
 constexpr uint32_t kSeqRound = 64;          // sequences per round
 constexpr uint32_t kWinUnits = 128;         // circular window of the bitstream, 16-byte units (+ 1 mirror unit)
 constexpr uint32_t kWinAhead = 80;          // units kept loaded below the cursor of the round before last
@@ -1689,7 +1694,7 @@ __global__ __launch_bounds__(kSeqThreads) void k_sequences(BatchParams p)
     __shared__ uint8_t sLLbits[36], sMLbits[53];
     __shared__ SeqCtl ctl[kSeqJobs];
     __shared__ uint2 pub[2][kSeqJobs];         // per round parity and block: {cursor after the round, sequences decoded in it}
-    __shared__ uint32_t activeFlag[2];         // per round parity: some block still has sequences to decode in that round
+    __shared__ __attribute__((aligned(16))) uint32_t activeFlag[2][4];      // per round parity and chain wave: some block of its still has sequences to decode in that round
     __shared__ uint32_t zeroCell;              // the "table" of a block's fourth chain lane: its cell adds nothing to the sum of the quad
     uint32_t const tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
 #ifdef ZG_STAMPS
@@ -1697,13 +1702,17 @@ __global__ __launch_bounds__(kSeqThreads) void k_sequences(BatchParams p)
 #endif
     if (tid < 36) { sLLbase[tid] = c_LL_base[tid]; sLLbits[tid] = c_LL_bits[tid]; }
     if (tid < 53) { sMLbase[tid] = c_ML_base[tid]; sMLbits[tid] = c_ML_bits[tid]; }
-    if (tid == 0) { activeFlag[0] = 1; activeFlag[1] = 0; zeroCell = 0; }
+    if (tid < 8) activeFlag[tid >> 2][tid & 3] = (tid < (uint32_t)kChainWaves) ? 1u : 0u;
+    if (tid == 0) zeroCell = 0;
     wg_barrier();
 
     // ---------------- helper side set-up (waves 1-4): tables, window, per-block constants
     uint32_t const gl = lane & 15, lead = lane & ~15u;
-    bool const chain = wave == 0, helper = wave != 0;
-    uint32_t const slot = helper ? (wave - 1) * 4 + (lane >> 4) : (lane >> 2);       // block slot inside the workgroup
+    bool const chain = wave < (uint32_t)kChainWaves, helper = !chain;
+    // (with four chain waves only the first 16 lanes of each run chains: fewer addresses per LDS read, fewer bank conflicts)
+    bool const chainLane = chain && (kChainWaves == 1 || lane < 16);
+    uint32_t const slot = helper ? (wave - kChainWaves) * 4 + (lane >> 4)
+                                 : (kChainWaves == 1 ? (lane >> 2) : wave * 4 + ((lane >> 2) & 3));       // block slot inside the workgroup
     uint32_t const role = lane & 3;            // chain wave: which of a block's four chain lanes this is (LL, ML, OF, cursor)
     uint32_t const job = blockIdx.x * kSeqJobs + slot;
     bool const hasJob = job < n_seq_jobs(p);
@@ -1857,7 +1866,7 @@ __global__ __launch_bounds__(kSeqThreads) void k_sequences(BatchParams p)
     typedef const __attribute__((address_space(3))) uint32_t* lds_u32;
     typedef __attribute__((address_space(3))) uint32_t* lds_u32w;
     uint32_t const tabL = (uint32_t)(uintptr_t)(lds_u32)(role == 0 ? tLL : role == 1 ? tML : role == 2 ? tOF : &zeroCell);    // LDS byte address of this lane's table
-    if (chain) {
+    if (chainLane) {
         SeqCtl const c = ctl[slot];
         if (!c.fail) {
             remaining = c.nbSeq;
@@ -1893,10 +1902,11 @@ __global__ __launch_bounds__(kSeqThreads) void k_sequences(BatchParams p)
     for (uint32_t k = 0;; k++) {
         uint32_t const par = k & 1;
         bool act;
-        if (chain) act = chainAct; else act = activeFlag[par] != 0;
+        if (kChainWaves == 1) { if (chain) act = chainAct; else act = activeFlag[par][0] != 0; }
+        else { uint4 const f = *(const uint4*)activeFlag[par]; act = (f.x | f.y | f.z | f.w) != 0; }
         if (chain) {
             // ---- the serial chains, round k
-            if (act) {
+            if (act && chainLane) {
                 uint32_t n = 0;
                 uint32_t* const ring = ring0 + par * 4 * kSeqRound;
                 if (remaining) {
@@ -1973,7 +1983,7 @@ __global__ __launch_bounds__(kSeqThreads) void k_sequences(BatchParams p)
                 }
                 if (role == 0) pub[par][slot] = make_uint2(Q, n);
                 bool const anyLeft = __any(remaining != 0);
-                if (lane == 0) activeFlag[par ^ 1] = anyLeft ? 1u : 0u;
+                if (lane == 0) activeFlag[par ^ 1][wave] = anyLeft ? 1u : 0u;
                 chainAct = anyLeft;
             }
         } else if (helper && k >= 1 && !dead) {
@@ -3589,6 +3599,12 @@ __global__ __launch_bounds__(64) void k_xxh64(const uint8_t* base, const uint64_
 }
 
 // ---------------------------------------------------------------- dictionary digest (single lane)
+// Zero fill of a 16-byte aligned area whose size is a multiple of 16 (a kernel instead of a memset node: see launch_zero's callers)
+__global__ __launch_bounds__(256) void k_zero(uint4* p, size_t units)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < units; i += (size_t)gridDim.x * 256) p[i] = make_uint4(0, 0, 0, 0);
+}
+
 __global__ __launch_bounds__(64) void k_digest_dict(const uint8_t* dict, uint32_t dictSize, DevDict* out)
 {
     __shared__ __attribute__((aligned(16))) uint8_t scratch[2048];
@@ -3693,6 +3709,13 @@ void launch_digest_dict(const uint8_t* devDict, uint32_t dictSize, DevDict* out,
 void launch_basic_tables(uint32_t* out, void* stream)
 {
     hipLaunchKernelGGL(k_basic_tables, dim3(1), dim3(64), 0, (hipStream_t)stream, out);
+}
+void launch_zero(void* p, size_t bytes, void* stream)
+{
+    if (!bytes) return;
+    size_t const units = bytes / 16;
+    uint32_t const grid = (uint32_t)((units + 255) / 256 < 1024 ? (units + 255) / 256 : 1024);
+    hipLaunchKernelGGL(k_zero, dim3(grid ? grid : 1), dim3(256), 0, (hipStream_t)stream, (uint4*)p, units);
 }
 void launch_xxh64(const uint8_t* base, const uint64_t* off, const uint64_t* len, uint32_t n, uint64_t* out, void* stream)
 {

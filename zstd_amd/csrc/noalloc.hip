@@ -113,10 +113,12 @@ extern "C" size_t zstdgpu_decode_frames_noalloc(zstdgpu_ctx* ctx, const void* de
 
     // ---- descriptors, on the device (the previous call's are overwritten; block slots and states start at zero)
     launch_scan_frames((const uint8_t*)devSrc, srcBytes, (const FrameIn*)devFrames, nFrames, batchDictID, opts, frames, slots, totals, s, caps);
-    if (hipMemsetAsync(blocks, 0, (size_t)kMaxBlocks * sizeof(DevBlock), s) != hipSuccess ||
-        hipMemsetAsync(flags, 0, kMaxBlocks, s) != hipSuccess ||
-        hipMemsetAsync(state, 0, (size_t)kMaxBlocks * sizeof(DevBlockState), s) != hipSuccess ||
-        hipMemsetAsync(ptr + oDryList, 0, sizeof(uint32_t), s) != hipSuccess) return mkerr(E_generic);
+    // Zeroed by a kernel, not by memset nodes: the call is meant to be captured into a graph, and replayed from one a memset
+    // node of a few bytes (the eight totals, the dry list's count) was seen not to take effect on the second launch
+    // (ROCm 7.2, gfx950).  Block descriptors, block states and flags lie side by side.
+    static_assert(oBlocks < oState && oState < oFlags && oFlags < oLitJobs && (oLitJobs - oBlocks) % 16 == 0, "one zero fill covers blocks, states and flags");
+    launch_zero(ptr + oBlocks, oLitJobs - oBlocks, s);
+    launch_zero(ptr + oDryList, 16, s);
     launch_fill_blocks((const uint8_t*)devSrc, srcBytes, (const FrameIn*)devFrames, nFrames, batchDictID, opts, (ddict && ddict->hasEntropy) ? 1u : 0u,
                        frames, blocks, flags, kMaxBlocks, litJobs, seqJobs, totals, s, caps);
 

@@ -695,7 +695,7 @@ extern "C" zstdgpu_batch* zstdgpu_batch_create(zstdgpu_ctx* ctx, const void* hos
               dalloc(B->dFrames, nFrames, B->scratchBytes) && dalloc(B->dStatus, nFrames, B->scratchBytes) &&
               balloc(ctx, B->dLitBuf, B->litBytes, B->litBufBytes, B->scratchBytes) && balloc(ctx, B->dLitTmp, tmpOff + 64, B->litTmpBytes, B->scratchBytes) && balloc(ctx, B->dSeqBuf, seqOff * 4 + 4, B->seqBufBytes, B->scratchBytes) &&
               dalloc(B->dLitJobs, B->hLitJobs.size(), B->scratchBytes) && dalloc(B->dPackTab, B->hLitJobs.size() * 33 + 1, B->scratchBytes) && dalloc(B->dSeqJobs, B->hSeqJobs.size(), B->scratchBytes) &&
-              dalloc(B->dDryList, B->hSeqJobs.size() + 1, B->scratchBytes);
+              dalloc(B->dDryList, B->hSeqJobs.size() + 4, B->scratchBytes);
     auto up = [&](void* d, const void* h, size_t n) { return n == 0 || hipMemcpy(d, h, n, hipMemcpyHostToDevice) == hipSuccess; };
     ok = ok && up(B->dBlocks, B->hBlocks.data(), nBlocks * sizeof(DevBlock)) && up(B->dFrames, B->hFrames.data(), nFrames * sizeof(DevFrame)) &&
          up(B->dLitJobs, B->hLitJobs.data(), B->hLitJobs.size() * 4) && up(B->dSeqJobs, B->hSeqJobs.data(), B->hSeqJobs.size() * 4);
@@ -761,7 +761,7 @@ extern "C" zstdgpu_batch* zstdgpu_batch_create_on_device(zstdgpu_ctx* ctx, const
         B->litBytes = litOff + 64; B->nSeqTotal = seqOff;
         ok = balloc(ctx, B->dLitBuf, B->litBytes, B->litBufBytes, B->scratchBytes) && balloc(ctx, B->dLitTmp, tmpOff + 64, B->litTmpBytes, B->scratchBytes) &&
              balloc(ctx, B->dSeqBuf, seqOff * 4 + 4, B->seqBufBytes, B->scratchBytes) && dalloc(B->dPackTab, nLit * 33 + 1, B->scratchBytes) &&
-             dalloc(B->dDryList, nSeq + 1, B->scratchBytes);
+             dalloc(B->dDryList, nSeq + 4, B->scratchBytes);
         B->nFrames = nFrames; B->nBlocks = nBlocks; B->nLitJobs = (uint32_t)nLit; B->nSeqJobs = (uint32_t)nSeq;
         B->srcBytes = totals[6];
         B->mirrored = false;
@@ -837,8 +837,11 @@ extern "C" size_t zstdgpu_batch_decode(zstdgpu_batch* B, const void* devSrc, voi
     if (B->launched && s != B->lastStream) hipStreamWaitEvent(s, B->evDone, 0);
     bool const prof = B->profiling && B->evReady;
     if (prof) hipEventRecord(B->ev[0], s);
-    if (p.nBlocks) hipMemsetAsync(B->dState, 0, (size_t)p.nBlocks * sizeof(DevBlockState), s);
-    hipMemsetAsync(B->dDryList, 0, sizeof(uint32_t), s);
+    static_assert(sizeof(DevBlockState) % 16 == 0, "block states are zeroed 16 bytes at a time");
+    if (p.nBlocks) launch_zero(B->dState, (size_t)p.nBlocks * sizeof(DevBlockState), s);
+    // (a kernel, not a memset: replayed from a captured graph, a memset node of a few bytes was seen not to take effect on
+    // the second launch -- ROCm 7.2, gfx950; the list's first 16 bytes are its count and entries written before they are read)
+    launch_zero(B->dDryList, 16, s);
     launch_literals(p, s);
     if (prof) hipEventRecord(B->ev[1], s);
     // the pack of split-decoded literals needs nothing from the sequence stage and leaves it most of the chip: side stream

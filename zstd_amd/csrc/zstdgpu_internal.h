@@ -155,6 +155,7 @@ void launch_execute(const BatchParams& p, void* stream);
 void launch_checksum(const BatchParams& p, void* stream);
 void launch_digest_dict(const uint8_t* devDict, uint32_t dictSize, DevDict* out, void* stream);
 void launch_basic_tables(uint32_t* out /* [3][64][4] */, void* stream);
+void launch_zero(void* p /* 16-byte aligned */, size_t bytes /* multiple of 16 */, void* stream);
 void launch_xxh64(const uint8_t* base, const uint64_t* off, const uint64_t* len, uint32_t n, uint64_t* out, void* stream);
 
 }  // namespace zg
