@@ -262,6 +262,7 @@ __global__ __launch_bounds__(64) void k_fill_blocks(const uint8_t* src, uint64_t
                     if (d.ofType != SET_REPEAT) ofDef = (int32_t)b;
                     if (d.mlType != SET_REPEAT) mlDef = (int32_t)b;
                     d.llSrc = llDef; d.ofSrc = ofDef; d.mlSrc = mlDef;
+                    if (llDef != SRC_DICT || ofDef != SRC_DICT || mlDef != SRC_DICT) atomicAdd((unsigned long long*)&totals[8], 1ull);    // a job with a table of its own
                     d.seqBufOff = (uint64_t)d.nbSeq + 1 + 64;   // + the terminal record + 64 spare records
                     fl |= 2;
                 }
@@ -319,7 +320,7 @@ void launch_scan_frames(const uint8_t* src, uint64_t srcBytes, const FrameIn* in
                         DevFrame* frames, uint32_t* slots, uint64_t* totals, void* stream, ScratchCaps caps)
 {
     if (nFrames) hipLaunchKernelGGL(k_scan_frames, dim3((nFrames + 63) / 64), dim3(64), 0, (hipStream_t)stream, src, srcBytes, in, nFrames, batchDictID, opts, frames, slots);
-    launch_zero(totals, 8 * sizeof(uint64_t), stream);      // (a kernel: a memset node this small is not reliable in a replayed graph)
+    launch_zero(totals, 16 * sizeof(uint64_t), stream);      // (a kernel: a memset node this small is not reliable in a replayed graph)
     hipLaunchKernelGGL(k_first_blocks, dim3(1), dim3(kScanThreads), 0, (hipStream_t)stream, slots, in, nFrames, frames, totals, caps.maxBlocks);
 }
 

@@ -1687,9 +1687,19 @@ DEVI void peek64c(const uint32_t* win, uint32_t Q, uint32_t& tHi, uint32_t& tLo)
 // 16-byte unit at addr, kept inside [floor, ceil] (whatever lies outside is never interpreted)
 DEVI uint4 ld_unit(uintptr_t addr, uintptr_t floor, uintptr_t ceil) { return ld_unit(addr <= ceil ? addr : ceil, floor); }
 
-__global__ __launch_bounds__(kSeqThreads) void k_sequences(BatchParams p)
+// kDictTables: every job of the launch takes all three tables from the dictionary (small dictionary-compressed records:
+// the tables are then copied into LDS once per workgroup instead of once per block, which leaves room for two workgroups
+// -- two chain waves -- on a compute unit).
+// It is launched with eight waves, of which the last three end at once: a compute unit was seen to hold only ONE workgroup
+// of five waves with this much LDS (72 KB; 48 KB: two, not three), but two of eight or of four waves (tools/census).
+constexpr int kSeqLaunchThreadsDict = 64 * 8;
+constexpr uint32_t kSeqTabWords = 512 + 512 + 256;
+constexpr uint32_t kSeqOwnWords = kSeqJobWords - kSeqTabWords;      // window and rings of a job
+template <bool kDictTables>
+__global__ __launch_bounds__(kDictTables ? kSeqLaunchThreadsDict : kSeqThreads) void k_sequences(BatchParams p)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t lds[kSeqJobs * kSeqJobWords];
+    if (kDictTables && threadIdx.x >= (uint32_t)kSeqThreads) return;      // (waves that only make up the launch shape; they never reach a barrier)
+    __shared__ __attribute__((aligned(16))) uint32_t lds[kDictTables ? kSeqTabWords + kSeqJobs * kSeqOwnWords : kSeqJobs * kSeqJobWords];
     __shared__ uint32_t sLLbase[36], sMLbase[53];
     __shared__ uint8_t sLLbits[36], sMLbits[53];
     __shared__ SeqCtl ctl[kSeqJobs];
@@ -1716,10 +1726,19 @@ __global__ __launch_bounds__(kSeqThreads) void k_sequences(BatchParams p)
     uint32_t const role = lane & 3;            // chain wave: which of a block's four chain lanes this is (LL, ML, OF, cursor)
     uint32_t const job = blockIdx.x * kSeqJobs + slot;
     bool const hasJob = job < n_seq_jobs(p);
-    uint32_t* const tLL = lds + slot * kSeqJobWords;
+    uint32_t* const tLL = kDictTables ? lds : lds + slot * kSeqJobWords;
     uint32_t* const tML = tLL + 512;
     uint32_t* const tOF = tML + 512;
-    uint32_t* const win = tOF + 256;
+    uint32_t* const win = kDictTables ? lds + kSeqTabWords + slot * kSeqOwnWords : tOF + 256;
+    if (kDictTables) {
+        // the dictionary's three tables, once for the workgroup (16 bytes per thread and pass; whole arrays: cells past a
+        // table's size are never addressed)
+        const DevDict* const dd = p.dict;
+        for (uint32_t i = tid; i < kSeqTabWords / 4; i += kSeqThreads) {
+            const uint4* const from = i < 128 ? (const uint4*)dd->ll + i : i < 256 ? (const uint4*)dd->ml + (i - 128) : (const uint4*)dd->of + (i - 256);
+            ((uint4*)lds)[i] = *from;
+        }
+    }
     uint32_t* const ring0 = win + 4 * (kWinUnits + 1);
     uint32_t const b = hasJob ? p.seqJobs[job] : 0;
 
@@ -1744,15 +1763,18 @@ __global__ __launch_bounds__(kSeqThreads) void k_sequences(BatchParams p)
             static_assert(512 + kGrpBuildScratch <= 4 * (4 * (kWinUnits + 1) + 2 * 4 * kSeqRound), "table scratch fits");
             uint32_t const hdrAvail = off < blk.cSize ? blk.cSize - off : 0;
             uint32_t const nStaged = hdrAvail < 256 ? hdrAvail : 256;
-            grp_stage_bytes(hdr, payload + off, nStaged, gl);
-            lds_sync();
+            if (!kDictTables) {
+                grp_stage_bytes(hdr, payload + off, nStaged, gl);
+                lds_sync();
+            }
 #ifdef ZG_STAMPS
             if (gl == 0 && p.dbg) p.dbg[8 * (size_t)p.nBlocks + 8 * (size_t)b + 5] = __builtin_readcyclecounter() - k0;
 #endif
             bool fail = false;
             uint32_t done = 0;          // description bytes consumed so far
+            if (kDictTables) logsPacked = p.dict->llLog | (p.dict->ofLog << 8) | (p.dict->mlLog << 16);
 #pragma unroll 1      // (one copy of this code run three times: it is executed once per block, and instruction fetch is what it costs)
-            for (int t = 0; t < 3; t++) {
+            for (int t = 0; t < (kDictTables ? 0 : 3); t++) {
                 uint32_t const type = t == T_LL ? blk.llType : t == T_OF ? blk.ofType : blk.mlType;
                 int32_t const srcB = t == T_LL ? blk.llSrc : t == T_OF ? blk.ofSrc : blk.mlSrc;
                 uint32_t* const cells = t == T_LL ? tLL : t == T_OF ? tOF : tML;
@@ -3671,7 +3693,9 @@ void launch_pack_literals(const BatchParams& p, void* stream)
 void launch_sequences(const BatchParams& p, void* stream)
 {
     if (!p.nSeqJobs) return;
-    hipLaunchKernelGGL(k_sequences, dim3((p.nSeqJobs + kSeqJobs - 1) / kSeqJobs), dim3(kSeqThreads), 0, (hipStream_t)stream, p);
+    dim3 const grid((p.nSeqJobs + kSeqJobs - 1) / kSeqJobs);
+    if (p.seqTablesFromDict && p.dict) hipLaunchKernelGGL(k_sequences<true>, grid, dim3(kSeqLaunchThreadsDict), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(k_sequences<false>, grid, dim3(kSeqThreads), 0, (hipStream_t)stream, p);
 }
 void launch_sequences_dry(const BatchParams& p, void* stream)
 {

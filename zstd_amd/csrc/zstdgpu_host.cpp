@@ -172,6 +172,7 @@ struct zstdgpu_batch {
     uint8_t* dLitBuf = nullptr; uint8_t* dLitTmp = nullptr; uint4* dPackTab = nullptr; uint32_t* dSeqBuf = nullptr; uint32_t *dLitJobs = nullptr, *dSeqJobs = nullptr, *dDryList = nullptr;
     size_t litBufBytes = 0, litTmpBytes = 0, seqBufBytes = 0;      // real sizes of the two big buffers (they return to the context's spare list)
     uint64_t litBytes = 0, nSeqTotal = 0, srcBytes = 0, scratchBytes = 0;
+    bool seqTablesFromDict = false;   // every sequence job takes its three tables from the dictionary
     bool profiling = false;
     hipEvent_t ev[ZSTDGPU_NUM_STAGES + 1] = {};
     bool evReady = false, evRecorded = false;
@@ -634,6 +635,7 @@ extern "C" zstdgpu_batch* zstdgpu_batch_create(zstdgpu_ctx* ctx, const void* hos
     bool const dictEntropy = ddict && ddict->hasEntropy;
     uint32_t const batchDictID = ddict ? ddict->dictID : 0;
     uint64_t litOff = 0, seqOff = 0, tmpOff = 0;
+    uint32_t ownTables = 0;      // sequence jobs with a table that is not the dictionary's
     try {
     B->hBlocks.resize(nBlocks);
     B->hFrames.resize(nFrames);
@@ -682,6 +684,7 @@ extern "C" zstdgpu_batch* zstdgpu_batch_create(zstdgpu_ctx* ctx, const void* hos
                 if (d.ofType != SET_REPEAT) ofDef = (int32_t)b;
                 if (d.mlType != SET_REPEAT) mlDef = (int32_t)b;
                 d.llSrc = llDef; d.ofSrc = ofDef; d.mlSrc = mlDef;
+                if (llDef != SRC_DICT || ofDef != SRC_DICT || mlDef != SRC_DICT) ownTables++;
                 d.seqBufOff = seqOff;
                 seqOff += (uint64_t)d.nbSeq + 1 + 64;   // + the terminal record + 64 spare records (the sequence kernel stores whole rounds)
                 B->hSeqJobs.push_back(b);
@@ -691,6 +694,7 @@ extern "C" zstdgpu_batch* zstdgpu_batch_create(zstdgpu_ctx* ctx, const void* hos
     } catch (...) { drop_batch(B); return nullptr; }      // the C ABI never throws
     B->litBytes = litOff + 64; B->nSeqTotal = seqOff;
     B->nFrames = nFrames; B->nBlocks = nBlocks; B->nLitJobs = (uint32_t)B->hLitJobs.size(); B->nSeqJobs = (uint32_t)B->hSeqJobs.size();
+    B->seqTablesFromDict = dictEntropy && B->nSeqJobs != 0 && ownTables == 0;
     bool ok = dalloc(B->dBlocks, nBlocks, B->scratchBytes) && dalloc(B->dState, nBlocks, B->scratchBytes) &&
               dalloc(B->dFrames, nFrames, B->scratchBytes) && dalloc(B->dStatus, nFrames, B->scratchBytes) &&
               balloc(ctx, B->dLitBuf, B->litBytes, B->litBufBytes, B->scratchBytes) && balloc(ctx, B->dLitTmp, tmpOff + 64, B->litTmpBytes, B->scratchBytes) && balloc(ctx, B->dSeqBuf, seqOff * 4 + 4, B->seqBufBytes, B->scratchBytes) &&
@@ -736,11 +740,11 @@ extern "C" zstdgpu_batch* zstdgpu_batch_create_on_device(zstdgpu_ctx* ctx, const
     uint32_t const batchDictID = ddict ? ddict->dictID : 0;
     FrameIn* dIn = nullptr; uint32_t* dSlots = nullptr; uint64_t* dTotals = nullptr; uint8_t* dFlags = nullptr;
     uint64_t tmpAcct = 0;
-    uint64_t totals[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t totals[16] = {};
     uint32_t nBlocks = 0;
     auto cleanup = [&]() { hipFree(dIn); hipFree(dSlots); hipFree(dTotals); hipFree(dFlags); };
     bool ok = dalloc(B->dFrames, nFrames, B->scratchBytes) && dalloc(B->dStatus, nFrames, B->scratchBytes) &&
-              dalloc(dIn, nFrames, tmpAcct) && dalloc(dSlots, nFrames, tmpAcct) && dalloc(dTotals, 8, tmpAcct);
+              dalloc(dIn, nFrames, tmpAcct) && dalloc(dSlots, nFrames, tmpAcct) && dalloc(dTotals, 16, tmpAcct);
     ok = ok && (nFrames == 0 || hipMemcpy(dIn, in, (size_t)nFrames * sizeof(FrameIn), hipMemcpyHostToDevice) == hipSuccess);
     if (ok) {
         launch_scan_frames((const uint8_t*)devSrc, srcBytes, dIn, nFrames, batchDictID, (ddict ? (uint32_t)kOptDict : 0u) | ctx->opts(), B->dFrames, dSlots, dTotals, nullptr);
@@ -764,6 +768,7 @@ extern "C" zstdgpu_batch* zstdgpu_batch_create_on_device(zstdgpu_ctx* ctx, const
              dalloc(B->dDryList, nSeq + 4, B->scratchBytes);
         B->nFrames = nFrames; B->nBlocks = nBlocks; B->nLitJobs = (uint32_t)nLit; B->nSeqJobs = (uint32_t)nSeq;
         B->srcBytes = totals[6];
+        B->seqTablesFromDict = ddict && ddict->hasEntropy && nSeq != 0 && totals[8] == 0;
         B->mirrored = false;
     }
     ok = ok && hipStreamCreateWithFlags(&B->side, hipStreamNonBlocking) == hipSuccess &&
@@ -822,6 +827,7 @@ extern "C" size_t zstdgpu_batch_decode(zstdgpu_batch* B, const void* devSrc, voi
     p.nLitJobs = B->nLitJobs; p.nSeqJobs = B->nSeqJobs;
     p.nFrames = B->nFrames; p.nBlocks = B->nBlocks;
     p.execMode = B->ctx ? B->ctx->execKernel : 0u;
+    p.seqTablesFromDict = B->seqTablesFromDict ? 1u : 0u;
     if (B->ddict) {
         p.dict = B->ddict->dDict;
         p.dictContent = B->ddict->dBytes + B->ddict->entropySize;
