@@ -254,6 +254,7 @@ __global__ __launch_bounds__(64) void k_fill_blocks(const uint8_t* src, uint64_t
                 if (d.litType >= SET_COMPRESSED) {
                     d.litBufOff = (d.litSize + 15) & ~15ull;
                     if (!d.singleStream) d.litTmpOff = litTmpBytes(d.litSize);
+                    if (!d.singleStream || d.hufSrc != SRC_DICT) atomicAdd((unsigned long long*)&totals[9], 1ull);    // not a single stream on the dictionary's table
                     fl |= 1;
                 }
                 if (d.hostSeqErr) dead = true;

@@ -575,17 +575,31 @@ DEVI void huf_flush(uint8_t* out, const uint8_t* outStage, const HufGeo& g, uint
     }
 }
 
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_literals(BatchParams p)
+// kDictTable: every job of the launch is a single stream coded with the dictionary's table (small dictionary-compressed
+// records).  One lane decodes such a stream, so the number of jobs a compute unit holds is what counts: the table is
+// copied into LDS once per workgroup of 32 jobs (eight waves), not once per job, which lets a compute unit hold 64 jobs
+// instead of 16.
+constexpr int kHufDictWaves = 8;
+constexpr int kHufDictJobs = kHufDictWaves * kHufJobs;
+template <bool kDictTable>
+__global__ __launch_bounds__(kDictTable ? 64 * kHufDictWaves : 64) __attribute__((amdgpu_waves_per_eu(kDictTable ? 4 : 1, kDictTable ? 4 : 2))) void k_literals(BatchParams p)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[kHufJobs * kHufJobBytes];
-    uint32_t const lane = threadIdx.x;
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kDictTable ? kHufTabBytes + kHufDictJobs * kHufStageBytes : kHufJobs * kHufJobBytes];
+    uint32_t const lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t const sub = lane / kHufLanes, sl = lane % kHufLanes;
-    uint32_t const job = blockIdx.x * kHufJobs + sub;
+    if (kDictTable) {
+        // the dictionary's table, whole (its array holds 2^12 cells whatever its log), 16 bytes per thread
+        static_assert(kHufTabBytes == 16 * 64 * kHufDictWaves, "one pass copies the table");
+        ((uint4*)lds)[threadIdx.x] = ((const uint4*)p.dict->huf)[threadIdx.x];
+        __syncthreads();
+    }
+    uint32_t const job = kDictTable ? blockIdx.x * kHufDictJobs + wave * kHufJobs + sub : blockIdx.x * kHufJobs + sub;
     if (job >= n_lit_jobs(p)) return;
     uint32_t const b = p.litJobs[job];
     DevBlock const blk = p.blocks[b];
-    uint8_t* const tab = lds + sub * kHufJobBytes;
-    uint16_t* const cells = (uint16_t*)tab;
+    // (with the shared table a job's own area is the stage area alone: `tab` is placed so that the offsets below still hold)
+    uint8_t* const tab = kDictTable ? lds + (wave * kHufJobs + sub) * kHufStageBytes : lds + sub * kHufJobBytes;
+    uint16_t* const cells = kDictTable ? (uint16_t*)lds : (uint16_t*)tab;
     uint8_t* const weights = tab + kHufTabBytes;                       // table-build scratch, dead once the table is filled
     uint16_t* const pos = (uint16_t*)(tab + kHufTabBytes + 256);
     uint32_t* const rank = (uint32_t*)(tab + kHufTabBytes + 768);
@@ -602,7 +616,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
     // (zstd_decompressf.pas:1288) and where HUF_selectDecoder picked it for the block that defined the table (four
     // streams only: a single-stream block always builds the single-symbol table, huf_decompress.pas:1386).
     bool x2 = fromDict;
-    if (blk.hufSrc >= 0) {
+    if (!kDictTable && blk.hufSrc >= 0) {
         uint32_t dSingle = blk.singleStream, dLit = blk.litSize, dC = blk.litCSize;
         if (blk.hufSrc != (int32_t)b) { const DevBlock* const sbp = p.blocks + blk.hufSrc; dSingle = sbp->singleStream; dLit = sbp->litSize; dC = sbp->litCSize; }
         x2 = !dSingle && dLit != 0 && huf_select_x2(dLit, dC);
@@ -611,7 +625,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
     // 8 bytes before it that the backward bit reader may touch (block and literals headers always precede it).
     uint8_t* const hdrStage = tab + 2048;
     uint32_t descAvail = 0;
-    if (blk.hufSrc >= 0) {
+    if (!kDictTable && blk.hufSrc >= 0) {
         DevBlock const sb = (blk.hufSrc == (int32_t)b) ? blk : p.blocks[blk.hufSrc];
         const uint8_t* const dp = p.src + sb.srcOff + sb.litHdrSize;
         descAvail = sb.litCSize < 136 ? sb.litCSize : 136;
@@ -623,6 +637,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
     if (sl == 0) {
         if (blk.litType == SET_COMPRESSED && !blk.singleStream && (blk.litSize == 0 || blk.litCSize == 0)) err = E_corruption;   // huf_decompress.pas:1421-1424
         else if (blk.hufSrc == SRC_NONE) err = E_corruption;
+        else if (kDictTable && !fromDict) err = E_generic;      // (not launched on such a batch)
         else if (fromDict) tableLog = p.dict->hufLog;
         else {
             DevBlock const sb = (blk.hufSrc == (int32_t)b) ? blk : p.blocks[blk.hufSrc];
@@ -650,7 +665,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
     uint16_t* const x1 = cells;
     if (ok) {
         // table fill (HUF_readDTableX1_wksp second half): cell = {symbol, nbBits = tableLog + 1 - weight}
-        if (fromDict) {
+        if (kDictTable) {
+        } else if (fromDict) {
             // 16 bytes per lane and pass, four passes' loads ahead of their stores (both arrays hold 4096 cells and are
             // 16-byte aligned: a short table is copied rounded up)
             uint32_t const units = ((2u << tableLog) + 15) >> 4;
@@ -731,7 +747,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
     // the literal buffer.  If the totals disagree with the stream's symbol count, or a scratch region overflows, the
     // block is decoded again stream by stream below (which also yields the verdict for corrupt streams).
     bool specDone = false;
-    {
+    if (!kDictTable) {
         uint32_t const k = sl & 3, j = sl >> 2;
         int T = 0;
         bool sbad = !ok || nStreams != 4 || p.litTmp == nullptr || mySize == 0 || tableLog > 11;    // (a 2^12 table leaves no LDS for the windows)
@@ -3683,7 +3699,8 @@ __global__ __launch_bounds__(64) void k_digest_dict(const uint8_t* dict, uint32_
 void launch_literals(const BatchParams& p, void* stream)
 {
     if (!p.nLitJobs) return;
-    hipLaunchKernelGGL(k_literals, dim3((p.nLitJobs + kHufJobs - 1) / kHufJobs), dim3(64), 0, (hipStream_t)stream, p);
+    if (p.litDictSingleStream && p.dict) hipLaunchKernelGGL(k_literals<true>, dim3((p.nLitJobs + kHufDictJobs - 1) / kHufDictJobs), dim3(64 * kHufDictWaves), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(k_literals<false>, dim3((p.nLitJobs + kHufJobs - 1) / kHufJobs), dim3(64), 0, (hipStream_t)stream, p);
 }
 void launch_pack_literals(const BatchParams& p, void* stream)
 {

@@ -173,6 +173,7 @@ struct zstdgpu_batch {
     size_t litBufBytes = 0, litTmpBytes = 0, seqBufBytes = 0;      // real sizes of the two big buffers (they return to the context's spare list)
     uint64_t litBytes = 0, nSeqTotal = 0, srcBytes = 0, scratchBytes = 0;
     bool seqTablesFromDict = false;   // every sequence job takes its three tables from the dictionary
+    bool litDictSingleStream = false; // every literal job is a single stream coded with the dictionary's table
     bool profiling = false;
     hipEvent_t ev[ZSTDGPU_NUM_STAGES + 1] = {};
     bool evReady = false, evRecorded = false;
@@ -636,6 +637,7 @@ extern "C" zstdgpu_batch* zstdgpu_batch_create(zstdgpu_ctx* ctx, const void* hos
     uint32_t const batchDictID = ddict ? ddict->dictID : 0;
     uint64_t litOff = 0, seqOff = 0, tmpOff = 0;
     uint32_t ownTables = 0;      // sequence jobs with a table that is not the dictionary's
+    uint32_t otherLits = 0;      // literal jobs that are not a single stream coded with the dictionary's table
     try {
     B->hBlocks.resize(nBlocks);
     B->hFrames.resize(nFrames);
@@ -676,6 +678,7 @@ extern "C" zstdgpu_batch* zstdgpu_batch_create(zstdgpu_ctx* ctx, const void* hos
                 d.litBufOff = litOff;
                 litOff += (d.litSize + 15) & ~15ull;
                 if (!d.singleStream) { d.litTmpOff = tmpOff; tmpOff += litTmpBytes(d.litSize); }
+                if (!d.singleStream || d.hufSrc != SRC_DICT) otherLits++;
                 B->hLitJobs.push_back(b);
             }
             if (d.hostSeqErr) { dead = true; continue; }
@@ -695,6 +698,7 @@ extern "C" zstdgpu_batch* zstdgpu_batch_create(zstdgpu_ctx* ctx, const void* hos
     B->litBytes = litOff + 64; B->nSeqTotal = seqOff;
     B->nFrames = nFrames; B->nBlocks = nBlocks; B->nLitJobs = (uint32_t)B->hLitJobs.size(); B->nSeqJobs = (uint32_t)B->hSeqJobs.size();
     B->seqTablesFromDict = dictEntropy && B->nSeqJobs != 0 && ownTables == 0;
+    B->litDictSingleStream = dictEntropy && B->nLitJobs != 0 && otherLits == 0;
     bool ok = dalloc(B->dBlocks, nBlocks, B->scratchBytes) && dalloc(B->dState, nBlocks, B->scratchBytes) &&
               dalloc(B->dFrames, nFrames, B->scratchBytes) && dalloc(B->dStatus, nFrames, B->scratchBytes) &&
               balloc(ctx, B->dLitBuf, B->litBytes, B->litBufBytes, B->scratchBytes) && balloc(ctx, B->dLitTmp, tmpOff + 64, B->litTmpBytes, B->scratchBytes) && balloc(ctx, B->dSeqBuf, seqOff * 4 + 4, B->seqBufBytes, B->scratchBytes) &&
@@ -769,6 +773,7 @@ extern "C" zstdgpu_batch* zstdgpu_batch_create_on_device(zstdgpu_ctx* ctx, const
         B->nFrames = nFrames; B->nBlocks = nBlocks; B->nLitJobs = (uint32_t)nLit; B->nSeqJobs = (uint32_t)nSeq;
         B->srcBytes = totals[6];
         B->seqTablesFromDict = ddict && ddict->hasEntropy && nSeq != 0 && totals[8] == 0;
+        B->litDictSingleStream = ddict && ddict->hasEntropy && nLit != 0 && totals[9] == 0;
         B->mirrored = false;
     }
     ok = ok && hipStreamCreateWithFlags(&B->side, hipStreamNonBlocking) == hipSuccess &&
@@ -828,6 +833,7 @@ extern "C" size_t zstdgpu_batch_decode(zstdgpu_batch* B, const void* devSrc, voi
     p.nFrames = B->nFrames; p.nBlocks = B->nBlocks;
     p.execMode = B->ctx ? B->ctx->execKernel : 0u;
     p.seqTablesFromDict = B->seqTablesFromDict ? 1u : 0u;
+    p.litDictSingleStream = B->litDictSingleStream ? 1u : 0u;
     if (B->ddict) {
         p.dict = B->ddict->dDict;
         p.dictContent = B->ddict->dBytes + B->ddict->entropySize;

@@ -118,6 +118,7 @@ struct BatchParams {
     const uint8_t* dictContent;  // device pointer to dictionary content
     uint32_t dictContentSize;
     uint32_t nLitJobs, nSeqJobs, nFrames, nBlocks;
+    uint32_t litDictSingleStream;  // 1: every literal job of the batch is a single stream coded with the dictionary's table (known to the host)
     uint32_t seqTablesFromDict;  // 1: every sequence job of the batch takes its three tables from the dictionary (known to the host)
     uint32_t execMode;           // which execute kernel takes a frame: 0 by its shape, 1 always one wave, 2 always eight (the caller's wish on
                                  // entry to launch_execute, which settles the 0 case by the size of the batch)
@@ -140,7 +141,7 @@ struct ScratchCaps { uint32_t maxBlocks; uint64_t litBytes, tmpBytes, seqRecords
 // descriptor builder on the device (descriptors.hip).  totals: [0] block slots, [1] literal buffer bytes,
 // [2] split-decode scratch bytes, [3] sequence records, [4] literal jobs, [5] sequence jobs, [6] source bytes of the
 // frames without a header error, [7] the batch exceeds the scratch capacities, [8] sequence jobs with a table that is not the
-// dictionary's (16 entries, the rest unused)
+// dictionary's, [9] literal jobs other than a single stream coded with the dictionary's table (16 entries, the rest unused)
 void launch_scan_frames(const uint8_t* src, uint64_t srcBytes, const FrameIn* in, uint32_t nFrames, uint32_t batchDictID, uint32_t opts,
                         DevFrame* frames, uint32_t* slots, uint64_t* totals, void* stream, ScratchCaps caps = ScratchCaps{0, 0, 0, 0});
 void launch_fill_blocks(const uint8_t* src, uint64_t srcBytes, const FrameIn* in, uint32_t nFrames, uint32_t batchDictID, uint32_t opts,
