@@ -2608,6 +2608,11 @@ constexpr uint32_t kOutKeep = kOutHist - kOutStage;     // history kept when the
 constexpr uint32_t kLitStage = ZG_LIT_STAGE;     // literal bytes of one batch staged in LDS
 static_assert(kOutStage <= kOutHist && kOutStage % 16 == 0 && kOutHist % 16 == 0 && kLitStage % 16 == 0 && kLitStage <= 1024, "stage sizes");
 
+// kMatch64: plain matches of up to 64 bytes (instead of 32) are assembled in LDS too, in a second step.  Worth its
+// instructions where such matches turn up in most batches -- records compressed against a dictionary, whose matches into
+// the dictionary run long -- and a loss elsewhere (the step is never taken, but its code costs the usual path registers):
+// the launcher picks the variant by whether the batch has a dictionary.
+template <bool kMatch64>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_execute(BatchParams p)
 {
     // The output stage holds the batch being assembled and, before it, what the batches before it produced (as long as
@@ -2745,14 +2750,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
             // bytes whatever its length, which must stay inside the frame's output area or the dictionary.
             q.lit0 = lane_value(q.lstart, 0);
             q.sumLL = endZ - q.lit0;          // the literals of a batch are contiguous
-            int64_t const fetchEnd = q.absS + (q.ml > 16 ? 32 : 16);
+            // (16 bytes at a time: up to 32 with the batch's other loads, the rest of a match of up to 64 bytes in a second step)
+            int64_t const fetchEnd = q.absS + ((kMatch64 && q.ml > 48) ? 64 : (kMatch64 && q.ml > 32) ? 48 : q.ml > 16 ? 32 : 16);
             bool const fetchable = q.plain & (q.absS >= 0 ? fetchEnd <= (int64_t)cap : fetchEnd <= 0);
             uint32_t const slowS = (q.have & !fetchable) ? q.ml : 0;
             // of a match handled in LDS, the leading bytes whose source lies before the batch come from memory, one per lane
             int64_t const lead = -ms < (int64_t)(q.ml < q.off ? q.ml : q.off) ? -ms : (int64_t)(q.ml < q.off ? q.ml : q.off);
             q.gcnt = ((slowS != 0) & (lead > 0)) ? (uint32_t)lead : 0u;
             q.gEnd = wave_incl_scan(q.gcnt);
-            bool const longRun = __any((q.ll > 32) | (q.plain & (q.ml > 32)));
+            bool const longRun = __any((q.ll > 32) | (q.plain & (q.ml > (kMatch64 ? 64u : 32u))));
             q.staged = (q.total <= kOutStage) & (q.sumLL <= kLitStage) & (lane_value(q.gEnd, 63) <= 64) & !longRun;
             // the batch goes right behind the previous one; when the stage is full the last kOutKeep bytes of history move to
             // the front first (`shift` = how far)
@@ -2794,7 +2800,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
             // plain match, single bytes for source bytes before the batch of the other matches
             // Every lane issues every load, on a harmless address (the block's records) when it has nothing to fetch: a fixed
             // number of loads in flight lets the waits further down be counted instead of draining everything.
-            uint32_t const fastLen = (staged && fastS) ? ml : 0;
+            uint32_t const fastLen = (staged && fastS) ? (ml < 32 ? ml : 32u) : 0;      // fetched with the batch's loads; the rest further down
             uint32_t const litFull = sumLL >> 4, litTail = sumLL & 15;
             const uint8_t* const safe = (const uint8_t*)recs;
             const uint8_t* const litG = litBase + lit0;
@@ -2857,9 +2863,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
                 lds_sync();
 #ifndef ZG_X_NORUNS
                 lds_copy_runs(outB + start, litStage + (litRle ? 0u : lstart - lit0), ll,
-                              outB + start + ll, nearS ? outB + start + ll - off : matStage + 32 * lane, nearS ? ml : fastLen);
+                              outB + start + ll, nearS ? outB + start + ll - off : matStage + 32 * lane, nearS ? (ml < 32 ? ml : 32u) : fastLen);
 #endif
                 if (gdst != 0xFFFFFFFFu) outB[gdst] = gv;
+                // ---- plain matches of 33 to 64 bytes: bytes 32 and up, the same way (short dictionary-compressed records have
+                // such a match in nearly every batch; without this step the whole batch would go from memory to memory)
+                if (kMatch64) {
+                    bool const longM = (fastS | nearS) & (ml > 32);
+                    if (__any(longM)) {
+                        uint32_t const rest = longM ? ml - 32 : 0u;
+                        bool const far = longM & fastS;
+                        uint4 w0, w1;
+                        __builtin_memcpy(&w0, far ? matSrc + 32 : safe, 16);
+                        __builtin_memcpy(&w1, (far && rest > 16) ? matSrc + 48 : safe, 16);
+                        lds_sync();       // the first 32 bytes have left the match stage
+                        if (far) { *(uint4*)(matStage + 32 * lane) = w0; if (rest > 16) *(uint4*)(matStage + 32 * lane + 16) = w1; }
+                        lds_sync();
+                        lds_copy_runs(outB + start + ll + 32, nearS ? outB + start + ll + 32 - off : matStage + 32 * lane, rest, outB, litStage, 0u);
+                    }
+                }
 #ifdef ZG_STAMPS
                 xa = __builtin_readcyclecounter();
 #endif
@@ -3736,7 +3758,10 @@ void launch_execute(const BatchParams& pIn, void* stream)
     uint32_t const forced = pIn.execMode <= 2 ? pIn.execMode : 0u;
     p.execMode = forced ? forced : (p.nFrames > kWfMaxFrames ? 1u : 0u);
     if (p.execMode != 1) hipLaunchKernelGGL(k_execute_wf, dim3(p.nFrames), dim3(64 * kWf), 0, (hipStream_t)stream, p);
-    if (p.execMode != 2) hipLaunchKernelGGL(k_execute, dim3(p.nFrames), dim3(64), 0, (hipStream_t)stream, p);
+    if (p.execMode != 2) {
+        if (p.dict) hipLaunchKernelGGL(k_execute<true>, dim3(p.nFrames), dim3(64), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL(k_execute<false>, dim3(p.nFrames), dim3(64), 0, (hipStream_t)stream, p);
+    }
 }
 void launch_checksum(const BatchParams& p, void* stream)
 {
