@@ -284,6 +284,7 @@ def main():
     ap.add_argument("--level", type=int, default=0, help="compression level; 0 = the configuration's own")
     ap.add_argument("--total-gb", type=float, default=64.0, help="config 4: output bytes of the whole job, in GB")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-latency", action="store_true", help="skip the one-shot latency leg (profiling runs: its hundreds of tiny launches would swamp the per-kernel averages)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -423,7 +424,7 @@ def main():
     # configuration from these very kernel sources; a profile of other code says nothing about this run
     traffic, traffic_from = None, None
     digest = kernel_source_digest()
-    for tag in ("r02",):
+    for tag in ("r03", "r02"):
         summ = os.path.join(ROOT, "profiles", f"{tag}_config{args.config}_summary.json")
         if os.path.exists(summ) and not args.frames and not args.level:
             js = json.load(open(summ))
@@ -449,7 +450,7 @@ def main():
         "pcie_inclusive_GBps": round(e2e, 2) if e2e else None,
         "scratch_bytes": batch.scratch_bytes, "kernel_source_digest": digest,
     }
-    if world == 1:
+    if world == 1 and not args.no_latency:
         out["one_shot_latency"] = one_shot_latency(dctx)
     if world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(frames, caps, w["dictionary"])

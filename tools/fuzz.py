@@ -78,9 +78,20 @@ def run(args, dctx=None) -> int:
     assert torch.cuda.is_available()
     dctx = dctx or api.DCtx(0)
     tls = {}
-    use_dict = getattr(args, "dict", False)
+    use_dict = getattr(args, "dict", False) or getattr(args, "records", False)
+    records = getattr(args, "records", False)
     dictionary, ddict = None, None
-    if use_dict:
+    rec_pool = None
+    if records:
+        # batches of small structured records, all compressed against one dictionary trained on such records: every block
+        # takes its Huffman and sequence tables from the dictionary, the shape that gets the kernels' shared-table variants
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import gen_fixtures
+        zt = corpus.SystemZstd()
+        rec_pool = gen_fixtures.records(1000 + args.seed, 1000 + args.rounds * args.frames)
+        dictionary = zt.train_dictionary(rec_pool[:1000], 112640)
+        ddict = api.DDict(dctx, dictionary)
+    elif use_dict:
         # a dictionary trained on text and record samples; with --dict every frame is compressed with it (some without
         # a dictionary ID in the header) and sizes stay small, where a dictionary matters
         zt = corpus.SystemZstd()
@@ -107,7 +118,11 @@ def run(args, dctx=None) -> int:
             if rng.random() < 0.05:
                 n = int(rng.integers(0, 40))
             plain = gen_plain(rng, n)
+            if records:
+                plain = rec_pool[1000 + r * args.frames + i]
             level = int(rng.choice([-5, -1, 1, 1, 2, 3, 3, 3, 4, 5, 6, 7, 9, 12, 15, 19]))
+            if records:
+                level = 3
             if level >= 12 and n > 96 * 1024:
                 level = 3
             wlog = int(rng.integers(10, 24)) if rng.random() < 0.3 else 0
@@ -207,6 +222,7 @@ def main():
     ap.add_argument("--max-kb", type=int, default=400)
     ap.add_argument("--corrupt", action="store_true", help="damage every frame (1-3 random bytes) and compare verdicts and bytes with the system libzstd (and the CPU oracle with it)")
     ap.add_argument("--dict", action="store_true", help="small frames compressed with a trained dictionary")
+    ap.add_argument("--records", action="store_true", help="batches of 4 KB structured records compressed against a dictionary trained on such records (level 3)")
     bad = run(ap.parse_args())
     print("FUZZ", "FAILED" if bad else "OK")
     sys.exit(1 if bad else 0)

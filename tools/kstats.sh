@@ -2,7 +2,7 @@
 # Per-kernel average durations (rocprofv3 kernel trace): tools/kstats.sh -> stdout
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf gpurun_out/kstats
-timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kstats -- python3 bench.py --steps 5 --warmup 2 --no-cpu > gpurun_out/kstats.log 2>&1 || exit 1
+timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kstats -- python3 bench.py --steps 5 --warmup 2 --no-cpu --no-latency > gpurun_out/kstats.log 2>&1 || exit 1
 python3 - <<'PY'
 import csv, glob
 for f in glob.glob("gpurun_out/kstats/**/*kernel_stats.csv", recursive=True):

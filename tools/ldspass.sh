@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/ldsp
-timeout -s KILL 240 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_WAIT_INST_LDS --output-format csv -d gpurun_out/ldsp -- python3 bench.py --steps 3 --warmup 1 --no-cpu > gpurun_out/ldsp.log 2>&1 || exit 1
+timeout -s KILL 240 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_WAIT_INST_LDS --output-format csv -d gpurun_out/ldsp -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-latency > gpurun_out/ldsp.log 2>&1 || exit 1
 python3 - <<'PY'
 import csv, glob, collections, re
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()

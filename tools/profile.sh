@@ -8,7 +8,7 @@ cfg=${2:-2}
 out=gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-args="--config $cfg --steps 5 --warmup 2 --no-cpu"
+args="--config $cfg --steps 5 --warmup 2 --no-cpu --no-latency"
 timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py $args > $out/stats.log 2>&1 || exit 1
 timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 bench.py $args > $out/fetch.log 2>&1 || exit 1
 timeout -s KILL 240 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 bench.py $args > $out/write.log 2>&1 || exit 1

@@ -30,7 +30,7 @@ def main():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
     import bench      # the digest of the kernel sources: bench.py takes HBM traffic from a summary only when it matches
-    out = {"tag": tag, "config": cfg, "command": f"python3 bench.py --config {cfg} --steps 5 --warmup 2 --no-cpu",
+    out = {"tag": tag, "config": cfg, "command": f"python3 bench.py --config {cfg} --steps 5 --warmup 2 --no-cpu --no-latency",
            "kernel_source_digest": bench.kernel_source_digest(), "kernels": {}}
     stats = list(csv.DictReader(open(max(glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv")), key=os.path.getmtime))))
     for r in stats:
