@@ -66,6 +66,25 @@ def test_zstd_decompress_creates_its_own_context():
     assert api.ZSTD_decompress(read_frame(e), e["capacity"]) == regenerate(e["source"])
 
 
+def test_oneshot_input_beyond_the_fixed_scratch(dctx):
+    """The one-shot drop-ins decode small inputs inside a fixed scratch area; what does not fit it (here: more blocks than
+    its block array holds, and more sequences than its record area) is found on the device and decoded again as a batch,
+    with the same result as the oracle's."""
+    import struct
+    body = b"".join(struct.pack("<I", (0 << 1) | (1 if i == 1499 else 0))[:3] for i in range(1500))       # 1500 empty raw blocks
+    fr = struct.pack("<I", 0xFD2FB528) + bytes([0x20, 0x00]) + body
+    want, werr = oracle.decompress(fr, 16)
+    assert werr == 0 and want == b""
+    assert api.ZSTD_decompressDCtx(dctx, fr, 16) == b""
+    e = next(x for x in FRAMES if x["name"] == "manyseq_longcount_l19")
+    want, werr = oracle.decompress(read_frame(e), e["capacity"])
+    assert werr == 0
+    assert api.ZSTD_decompressDCtx(dctx, read_frame(e), e["capacity"]) == want
+    # and small inputs afterwards still take the fixed area
+    e = next(x for x in FRAMES if x["name"] == "text4096_l3_c1")
+    assert api.ZSTD_decompressDCtx(dctx, read_frame(e), e["capacity"]) == regenerate(e["source"])
+
+
 def test_config1_round_trip(dctx):
     """BASELINE config 1: level-1 frame of a 1 MB text buffer decodes to the original bytes."""
     e = next(x for x in FRAMES if x["name"] == "text1m_l1")

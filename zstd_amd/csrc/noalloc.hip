@@ -77,14 +77,12 @@ uint8_t* noalloc_scratch(int device)
     return ptrs[device];
 }
 
-}  // namespace zg
+size_t fixed_scratch_bytes() { return kScratchBytes; }
 
-using namespace zg;
-
-extern "C" size_t zstdgpu_decode_frames_noalloc(zstdgpu_ctx* ctx, const void* devSrc, size_t srcBytes,
-                                                const zstdgpu_frame_in* devFrames, uint32_t nFrames,
-                                                void* devDst, zstdgpu_frame_status* devStatus,
-                                                const zstdgpu_ddict* ddict, void* stream)
+// Device walk + stage chain inside a scratch area of fixed_scratch_bytes() at `ptr` (256-byte aligned): the body of the
+// entry point below, also used by the one-shot drop-ins with a scratch area that belongs to their context.
+size_t decode_frames_fixed(zstdgpu_ctx* ctx, uint8_t* ptr, const void* devSrc, size_t srcBytes, const zstdgpu_frame_in* devFrames, uint32_t nFrames,
+                           void* devDst, zstdgpu_frame_status* devStatus, const zstdgpu_ddict* ddict, void* stream)
 {
     auto mkerr = [](uint32_t code) { return (size_t)0 - (size_t)code; };
     if (!ctx || hipSetDevice(ctx->device) != hipSuccess) return mkerr(E_generic);
@@ -92,7 +90,6 @@ extern "C" size_t zstdgpu_decode_frames_noalloc(zstdgpu_ctx* ctx, const void* de
     if (nFrames == 0) return 0;
     if (!devSrc || !devFrames || !devDst || !devStatus) return mkerr(E_generic);
     if (ddict && ddict->status) return mkerr(ddict->status);
-    uint8_t* const ptr = ctx->scratch;         // this device's copy of `scratch` (looked up by zstdgpu_create)
     if (!ptr) return mkerr(E_memory_allocation);
     hipStream_t const s = (hipStream_t)stream;
 
@@ -144,4 +141,15 @@ extern "C" size_t zstdgpu_decode_frames_noalloc(zstdgpu_ctx* ctx, const void* de
     launch_execute(p, s);
     launch_checksum(p, s);
     return hipGetLastError() == hipSuccess ? 0 : mkerr(E_generic);
+}
+
+}  // namespace zg
+
+extern "C" size_t zstdgpu_decode_frames_noalloc(zstdgpu_ctx* ctx, const void* devSrc, size_t srcBytes,
+                                                const zstdgpu_frame_in* devFrames, uint32_t nFrames,
+                                                void* devDst, zstdgpu_frame_status* devStatus,
+                                                const zstdgpu_ddict* ddict, void* stream)
+{
+    // ctx->scratch: this device's copy of `scratch` (looked up by zstdgpu_create)
+    return zg::decode_frames_fixed(ctx, ctx ? ctx->scratch : nullptr, devSrc, srcBytes, devFrames, nFrames, devDst, devStatus, ddict, stream);
 }

@@ -382,7 +382,7 @@ extern "C" void zstdgpu_destroy(zstdgpu_ctx* ctx)
     for (auto* z : ctx->streams) stream_detach(z);
     for (auto* d : ctx->ddicts) d->ctx = nullptr;
     for (auto* b : ctx->batches) b->ctx = nullptr;
-    hipFree(ctx->dSrc); hipFree(ctx->dDst);
+    hipFree(ctx->dSrc); hipFree(ctx->dDst); hipFree(ctx->oneShotScratch); hipFree(ctx->oneShotIO);
     for (auto& sp : ctx->spare) hipFree(sp.p);
     delete ctx;
 }
@@ -1059,6 +1059,42 @@ bool ensure(uint8_t*& p, size_t& cap, size_t need)
     return true;
 }
 
+// One group of frames of a one-shot call, source already in ctx->dSrc, output into ctx->dDst.  Small inputs (the limits of
+// the no-allocation entry point) go through the device walk inside a fixed scratch area that the context allocates once:
+// no batch object, no allocation, no stream or event is made per call -- what a caller decoding one small frame per call
+// pays for otherwise (the reference's own per-call cost is the allocation of its context, zstd_decompressf.pas:977-988).
+// An input that does not fit that area is known on the device only (every frame comes back memory_allocation): it is
+// decoded again as a batch.  The two walks build the same descriptors, so the verdicts are the same either way.
+size_t decode_group(zstdgpu_ctx* ctx, const uint8_t* src, size_t srcSize, const zstdgpu_frame_in* in, uint32_t n, const zstdgpu_ddict* ddict,
+                    zstdgpu_frame_status* st)
+{
+    if (ctx->oneShotFixed && n <= ZSTDGPU_NOALLOC_MAX_FRAMES && srcSize <= ZSTDGPU_NOALLOC_MAX_SRC_BYTES) {
+        if (!ctx->oneShotTried) {
+            ctx->oneShotTried = true;
+            if (hipMalloc((void**)&ctx->oneShotScratch, fixed_scratch_bytes()) != hipSuccess) ctx->oneShotScratch = nullptr;
+            if (hipMalloc((void**)&ctx->oneShotIO, ZSTDGPU_NOALLOC_MAX_FRAMES * (sizeof(zstdgpu_frame_in) + sizeof(zstdgpu_frame_status))) != hipSuccess) ctx->oneShotIO = nullptr;
+            (void)hipGetLastError();
+        }
+        if (ctx->oneShotScratch && ctx->oneShotIO) {
+            zstdgpu_frame_in* const dIn = (zstdgpu_frame_in*)ctx->oneShotIO;
+            zstdgpu_frame_status* const dSt = (zstdgpu_frame_status*)(ctx->oneShotIO + ZSTDGPU_NOALLOC_MAX_FRAMES * sizeof(zstdgpu_frame_in));
+            if (hipMemcpy(dIn, in, (size_t)n * sizeof(zstdgpu_frame_in), hipMemcpyHostToDevice) != hipSuccess) return mkerr(E_generic);
+            size_t const rc = decode_frames_fixed(ctx, ctx->oneShotScratch, ctx->dSrc, srcSize, dIn, n, ctx->dDst, dSt, ddict, nullptr);
+            if (rc) return rc;
+            if (hipMemcpy(st, dSt, (size_t)n * sizeof(zstdgpu_frame_status), hipMemcpyDeviceToHost) != hipSuccess) return mkerr(E_generic);
+            bool refused = false;      // (no other path to this code: a frame with a header error keeps that error, the others are refused)
+            for (uint32_t k = 0; k < n; k++) refused = refused || st[k].errorCode == E_memory_allocation;
+            if (!refused) return 0;
+        }
+    }
+    zstdgpu_batch* B = zstdgpu_batch_create_from_frames(ctx, src, srcSize, in, n, ddict);
+    if (!B) return mkerr(E_memory_allocation);
+    size_t rc = zstdgpu_batch_decode(B, ctx->dSrc, ctx->dDst, nullptr);
+    if (!rc) rc = zstdgpu_batch_status(B, st);
+    zstdgpu_batch_destroy(B);
+    return rc;
+}
+
 // ZSTD_decompressMultiFrame (zstd_decompressf.pas:836-942) over the batched device path.
 size_t decompress_multi(zstdgpu_ctx* ctx, void* dst, size_t dstCapacity, const void* srcv, size_t srcSize, const zstdgpu_ddict* ddict)
 try {
@@ -1119,12 +1155,8 @@ try {
         }
         (void)overflow;
         uint32_t const n = (uint32_t)(j - i);
-        zstdgpu_batch* B = zstdgpu_batch_create_from_frames(ctx, src, srcSize, ins.data() + i, n, ddict);
-        if (!B) return mkerr(E_memory_allocation);
         std::vector<zstdgpu_frame_status> st(n);
-        size_t rc = zstdgpu_batch_decode(B, ctx->dSrc, ctx->dDst, nullptr);
-        if (!rc) rc = zstdgpu_batch_status(B, st.data());
-        zstdgpu_batch_destroy(B);
+        size_t const rc = decode_group(ctx, src, srcSize, ins.data() + i, n, ddict, st.data());
         if (rc) return rc;
         for (uint32_t k = 0; k < n; k++) {
             if (st[k].errorCode) {
@@ -1398,6 +1430,7 @@ extern "C" size_t zstdgpu_decompress(void* dst, size_t dstCapacity, const void* 
     if (hipGetDevice(&dev) != hipSuccess) return mkerr(E_generic);
     zstdgpu_ctx* ctx = zstdgpu_create(dev);
     if (!ctx) return mkerr(E_memory_allocation);
+    ctx->oneShotFixed = false;      // (a context that lives for one call: a scratch area of its own would cost more than it saves)
     size_t const r = decompress_multi(ctx, dst, dstCapacity, src, srcSize, nullptr);
     zstdgpu_destroy(ctx);
     return r;

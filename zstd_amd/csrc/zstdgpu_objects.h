@@ -28,6 +28,12 @@ struct zstdgpu_ctx {
     std::vector<zstdgpu_ddict*> ddicts;           // dictionaries created on it (they forget it when it is destroyed)
     std::vector<zstdgpu_batch*> batches;          // batches created on it (likewise)
     uint8_t* scratch = nullptr;                   // this device's fixed scratch array (zstdgpu_decode_frames_noalloc)
+    // the one-shot drop-ins decode small inputs inside a fixed scratch area of the context's own (allocated at the first
+    // such call), with the frame list and the verdicts in a small buffer beside it: nothing is allocated per call
+    uint8_t* oneShotScratch = nullptr;
+    uint8_t* oneShotIO = nullptr;                 // 256 frame entries, then 256 verdicts
+    bool oneShotTried = false;
+    bool oneShotFixed = true;                     // false for the context that zstdgpu_decompress makes for a single call
     uint32_t execKernel = 0;                      // zstdgpu_test_setExecuteKernel: 0 chosen per launch, 1 one wave per frame, 2 eight
     uint32_t opts() const { return (format ? zg::kOptMagicless : 0u) | (ignoreChecksum ? zg::kOptIgnoreChecksum : 0u); }
     void reset_parameters() { format = 0; maxWindowSize = (1ull << 27) + 1; stableOut = 0; ignoreChecksum = 0; }
@@ -45,4 +51,8 @@ struct zstdgpu_ddict {
 namespace zg {
 // This device's copy of the fixed scratch array of the no-allocation entry point (noalloc.hip); nullptr on failure.
 uint8_t* noalloc_scratch(int device);
+// The body of zstdgpu_decode_frames_noalloc on a scratch area of fixed_scratch_bytes() given by the caller (noalloc.hip).
+size_t fixed_scratch_bytes();
+size_t decode_frames_fixed(zstdgpu_ctx* ctx, uint8_t* scratch, const void* devSrc, size_t srcBytes, const zstdgpu_frame_in* devFrames, uint32_t nFrames,
+                           void* devDst, zstdgpu_frame_status* devStatus, const zstdgpu_ddict* ddict, void* stream);
 }  // namespace zg
