@@ -1,24 +1,6 @@
-# INTEGRATION — wiring `libzstdgpu.so` into the Free Pascal zstd port
-
-The library is a drop-in for the **one-shot decode path** only. The Pascal units keep frame and
-block-header parsing and dictionary bookkeeping; block bodies go to the GPU through the C ABI in
-`include/zstdgpu.h`. Nothing below could be compiled in the build image (no `fpc`); it is the binding a
-maintainer adds. The same calls are exercised from Python through `zstd_amd/api.py` (ctypes), which
-mirrors the reference's function names.
-
-## 1. Build and link
-
-```
-python -c "import __graft_entry__ as g; g.build()"      # hipcc --offload-arch=gfx950 -> zstd_amd/libzstdgpu.so
-fpc -Fl<dir of libzstdgpu.so> test.lpr                   # Free Pascal links by library name
-```
-
-## 2. Binding unit (`pascal/zstd_gpu.pas`)
-
-The unit below is the file `pascal/zstd_gpu.pas`; `pascal/zstd_gpu_descriptors.pas` is the Pascal twin of the library's
-descriptor builder (section 4).
-
-```pascal
+{ Binding unit for libzstdgpu.so (include/zstdgpu.h): the C ABI of the batched gfx950 zstd decoder, as the Free Pascal
+  port binds it.  Not compiled in the build image (it has no Free Pascal compiler); kept in step with the header by hand,
+  and with INTEGRATION.md section 2, which quotes it. }
 unit zstd_gpu;
 {$mode objfpc}{$H+}{$PACKRECORDS C}
 interface
@@ -150,94 +132,3 @@ function zstdgpu_buildDescriptors(hostSrc: pbyte; srcBytes: PtrUInt; frames_in: 
   frames: pzstdgpu_frame_desc; blocks: pzstdgpu_block_desc; blockCapacity: PtrUInt): PtrUInt; cdecl; external ZSTDGPU_LIB;
 implementation
 end.
-```
-
-## 3. The one-line switch (whole frames, host buffers)
-
-In `decompress/zstd_decompressf.pas`, `ZSTD_decompress` (`:977-988`) creates a `ZSTD_DCtx` per call and
-runs `ZSTD_decompressMultiFrame`. The drop-in keeps the signature and forwards:
-
-```pascal
-function ZSTD_decompress(dst:pbyte; dstCapacity:int32; const src:pbyte; srcSize:int32):int32;
-var r: PtrUInt;
-begin
-  r := zstdgpu_decompress(dst, PtrUInt(dstCapacity), src, PtrUInt(srcSize));
-  if zstdgpu_isError(r) <> 0 then
-    result := -int32(zstdgpu_getErrorCode(r))     { upstream convention: negative code }
-  else
-    result := int32(r);
-end;
-```
-
-Multi-frame input, skippable frames, dictionaries (`ZSTD_decompress_usingDDict`, `:1496`) and the
-error precedence of `ZSTD_decompressMultiFrame` (`:836-942`) are handled inside the library.
-
-## 4. The batched switch (descriptor builder stays in Pascal)
-
-`ZSTD_decompressFrame` (`:734-834`) keeps its loop; the three decode calls in the `case` (`:783-795`)
-become descriptor appends, and one launch decodes every queued frame:
-
-```pascal
-{ inside the block loop, after ZSTD_getcBlockSize (:774) and the size check (:780) }
-with blocks[nBlocks] do begin
-  srcOff    := QWord(ip - srcBase);          { first byte after the 3-byte block header }
-  cSize     := cBlockSize;                   { 1 for bt_rle }
-  origSize  := blockProperties.origSize;
-  frameIdx  := thisFrame;
-  blockType := ord(blockProperties.blockType);
-  lastBlock := blockProperties.lastBlock;
-  hostError := 0;                            { or the ZSTD_ErrorCode that stopped the walk, with blockType := 3 }
-end;
-inc(nBlocks);
-...
-{ after the loop: frames[thisFrame] gets srcOff/srcSize/dstOff/dstCapacity, fParams.frameContentSize,
-  fParams.checksumFlag and the little-endian trailer (MEM_readLE32(ip), :822) }
-...
-batch := zstdgpu_batch_create(ctx, srcBase, srcBytes, @frames[0], nFrames, @blocks[0], nBlocks, ddict);
-zstdgpu_batch_decode(batch, devSrc, devDst, nil);     { device copies of the same source / destination }
-zstdgpu_batch_status(batch, @status[0]);              { per frame: errorCode, regenSize, xxh64Low32 }
-```
-
-`zstdgpu_buildDescriptors` in the library is the C mirror of exactly this builder and is what the
-tests and `bench.py` drive (`tests/test_gpu_parity.py::test_batch_mixed_valid_and_corrupt[True]` goes
-through caller-built descriptors).
-
-When the compressed frames already sit in device memory (read by another GPU stage, or uploaded once),
-`zstdgpu_batch_create_on_device` takes only the list of frames (`srcOff, srcSize, dstOff, dstCapacity`) and
-walks the frame, block and section headers with device kernels — the work of `ZSTD_getFrameHeader_advanced`
-(`:281-395`), `ZSTD_findFrameSizeInfo` (`:566-639`) and the header parts of `ZSTD_decodeLiteralsBlock` /
-`ZSTD_decodeSeqHeaders` (`zstd_decompress_block.pas:243-274`, `:333-400`, `:708-742`), one lane per frame. Its
-descriptors are bit-identical to those of the host walk
-(`tests/test_gpu_parity.py::test_device_walk_equals_host_walk_on_every_fixture`, `…_on_damaged_headers`); for
-65 536 dictionary-compressed 4 KB records it takes 1.8 ms where the host walk takes 9.5 ms (decode: 1.9 ms).
-
-Dictionaries: `zstd_ddict.pas` keeps ownership of the dictionary bytes; `zstdgpu_createDDict` copies
-them to the GPU once and digests the entropy tables there (`ZSTD_loadDEntropy`, `:1261-1356`); frames whose
-`dictID` differs from the batch dictionary fail with `dictionary_wrong` as in `ZSTD_decodeFrameHeader`
-(`:541-563`).
-
-Streaming callers (`ZSTD_decompressStream`, `:1978-2359`) switch the same way: `zstdgpu_decompressStream` takes the
-reference's in/out buffer records and returns 0 at the end of every frame, a positive hint otherwise. It collects one
-whole frame before decoding it (the kernels work on frames, not on single blocks), so its memory use is one
-compressed frame plus its output, and output appears only when a frame is complete.
-
-Decoder parameters (`ZSTD_DCtx_setParameter`, `:1763-1807`) live in the context, as they do in the reference where a
-stream is the context: `ZSTD_d_format` (magicless frames) and `ZSTD_d_forceIgnoreChecksum` apply to
-`zstdgpu_decompressDCtx`, to streams and to batches built from frame entries (host or device walk);
-`ZSTD_d_windowLogMax` and `ZSTD_d_stableOutBuffer` apply to streams. `zstdgpu_DCtx_refDDict` sets the dictionary that
-`zstdgpu_decompressDCtx` and the streams use (`ZSTD_getDDict`, `:951-969`); `zstdgpu_initDStream` clears it and
-`zstdgpu_initDStream_usingDDict` sets it, as `ZSTD_initDStream*` do. A caller that builds its own descriptors for
-`zstdgpu_batch_create` applies the format and the checksum policy in its own walk.
-
-## 5. Threading and lifetime
-
-A context belongs to one host thread and one GPU (as a `ZSTD_DCtx` does). Use one context per GPU for
-multi-GPU hosts; frames are independent, so shard them across contexts — there is nothing to exchange
-between GPUs. `zstdgpu_batch_decode` is asynchronous on the given HIP stream and allocates nothing;
-`zstdgpu_batch_status` synchronises. Source and destination device buffers must stay valid until then.
-
-**Callers that cannot allocate** (a decode recorded into a HIP graph, a serving loop with a fixed memory budget) use
-`zstdgpu_decode_frames_noalloc(ctx, devSrc, srcBytes, devFrames, nFrames, devDst, devStatus, ddict, stream)`: frames,
-frame entries, output and verdicts all in device memory, scratch in a 22 MiB array the library holds per GPU. Limits:
-256 frames / 4 MiB of source per call (`parameter_outOfBound` beyond), 1024 blocks / 4 MiB of Huffman literals / 2^18
-sequence records (`memory_allocation` in every frame's status beyond); one call at a time per GPU.
