@@ -112,7 +112,7 @@ def make_workload(cfg: str, rank: int, world: int, n_frames: int, level: int, to
                     note=f"synthetic (seeded generators, compressed with libzstd {zver} level {lvl})",
                     workload=f"BASELINE config 2, multi-block variant: {n} level-{lvl} frames x 1 MiB per GPU (eight 128 KB blocks each); frames sharded over ranks, no collective")
     if cfg == "4":
-        t = n_frames or 2048
+        t = n_frames or 4096      # (a launch of 4096 frames fills the chip: 16 blocks per compute unit in every stage)
         lv = [(1, 3, 3, 5, 9, 19)[i % 6] for i in range(t)]
         ck = [bool((i // 6) & 1) for i in range(t)]
         plain_all = [corpus.mixed(40_000 + i, 131072) for i in range(t)]
