@@ -383,6 +383,35 @@ def main():
             assert host[o:o + len(plain[i])].tobytes() == plain[i]
         del d_plain, host
 
+    # ---- several batches in flight (reported aside, never the headline): the same frames as two / three batch objects with
+    # their own scratch and output, launched in turn on streams of their own, so that the compute units a kernel's short
+    # chains leave early are taken by another batch's kernels instead of idling until its longest chain ends
+    two = None
+    if replicas == 1 and not args.no_latency:
+        two = {}
+        extra = [(api.Batch(dctx, src, fin, ddict), torch.zeros(rep_stride, dtype=torch.uint8, device="cuda"), torch.cuda.Stream()) for _ in range(2)]
+        for nfl in (2, 3):
+            lanes = [(batch, d_dst, None)] + extra[: nfl - 1]
+
+            def launch_all():
+                for b_, dst_, s_ in lanes:
+                    b_.decode(d_src.data_ptr(), dst_.data_ptr(), s_.cuda_stream if s_ is not None else stream)
+            rounds = max(2, args.steps // nfl)
+            for _ in range(2):
+                launch_all()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(rounds):
+                launch_all()
+            torch.cuda.synchronize()
+            dtn = time.perf_counter() - t0
+            for b_, dst_, s_ in lanes[1:]:
+                assert not b_.status()["errorCode"].any() and torch.equal(d_dst[:dst_bytes], dst_[:dst_bytes])
+            two[f"{nfl}_batches"] = {"GBps": round(nfl * rounds * d_bytes / dtn / 1e9, 2), "launches": nfl * rounds, "ms_per_launch": round(dtn / (nfl * rounds) * 1e3, 4)}
+        for b_, dst_, s_ in extra:
+            b_.close()
+        del extra
+
     # ---- PCIe-inclusive figure (reported aside, never the headline): pinned host buffers, H2D + decode + D2H
     e2e = None
     if rank == 0 and replicas == 1:
@@ -448,6 +477,7 @@ def main():
         "whole_chain_frac_of_hbm_peak": round((job_c + job_d) / world / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
         "host_descriptor_build_ms": round(t_desc * 1e3, 2), "device_descriptor_build_ms": round(t_desc_dev * 1e3, 2), "host_descriptor_build_first_ms": round(t_desc_first * 1e3, 2),
         "pcie_inclusive_GBps": round(e2e, 2) if e2e else None,
+        "batches_in_flight": two,
         "scratch_bytes": batch.scratch_bytes, "kernel_source_digest": digest,
     }
     if world == 1 and not args.no_latency:
