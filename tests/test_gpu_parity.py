@@ -458,6 +458,40 @@ def test_every_fixture_through_each_execute_kernel(dctx, kernel):
         dctx.set_execute_kernel("auto")
 
 
+def test_batch_launched_on_two_streams_then_destroyed(dctx):
+    """A batch's scratch belongs to one launch at a time: a decode on another stream than the last one waits for that one
+    (an event of the batch), and destroying the batch right after an asynchronous decode waits for it too -- its buffers
+    go back to the context, where the next batch picks them up."""
+    import torch
+    entries = [e for e in FRAMES if e["name"] in ("text128k_l3_c0", "bin128k_l19_c1", "text1m_l1", "alpha16_l19", "text4096_l3_c1")]
+    frames = [read_frame(e) for e in entries]
+    src, fin, dst_bytes = api.pack_frames(frames, [e["capacity"] for e in entries])
+    d_src = torch.from_numpy(src).cuda()
+    want = [oracle.decompress(f, e["capacity"])[0] for f, e in zip(frames, entries)]
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(3):
+        b = api.Batch(dctx, src, fin, None)
+        d1 = torch.zeros(dst_bytes, dtype=torch.uint8, device="cuda")
+        d2 = torch.zeros(dst_bytes, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        b.decode(d_src.data_ptr(), d1.data_ptr(), s1.cuda_stream)
+        b.decode(d_src.data_ptr(), d2.data_ptr(), s2.cuda_stream)       # no wait in between
+        b.close()                                                        # no wait before
+        torch.cuda.synchronize()
+        for d in (d1, d2):
+            out = d.cpu().numpy()
+            for i, w in enumerate(want):
+                o = int(fin[i]["dstOff"])
+                assert out[o:o + len(w)].tobytes() == w
+
+
+def test_execute_kernel_knob_bounds(dctx):
+    with pytest.raises(api.ZstdError) as ex:
+        api._check(api.lib().zstdgpu_test_setExecuteKernel(dctx.h, 3))
+    assert ex.value.code == 42
+    dctx.set_execute_kernel("auto")
+
+
 def test_device_walk_with_dictionary(dctx):
     d = read_dict("dict16k")
     dd = api.DDict(dctx, d)
