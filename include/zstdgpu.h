@@ -244,6 +244,10 @@ uint32_t zstdgpu_batch_nFrames(const zstdgpu_batch* batch);
 uint32_t zstdgpu_batch_nBlocks(const zstdgpu_batch* batch);
 uint64_t zstdgpu_batch_srcBytes(const zstdgpu_batch* batch);      /* sum of frame srcSize (C) */
 uint64_t zstdgpu_batch_scratchBytes(const zstdgpu_batch* batch);  /* device scratch held */
+/* Which kernel variants the batch's shape selects (a fact of the descriptors, for tests and reports): bit 0 every sequence
+ * job takes its three tables from the dictionary, bit 1 every literal job is a single stream coded with the dictionary's
+ * Huffman table -- the launches then keep one copy of those tables per workgroup instead of one per block. */
+uint32_t zstdgpu_batch_kernelVariants(const zstdgpu_batch* batch);
 
 /* Per-stage timing of the next launches: when enabled, zstdgpu_batch_decode brackets each kernel
  * with HIP events on the launch stream; zstdgpu_batch_stage_ms (after zstdgpu_batch_status or a

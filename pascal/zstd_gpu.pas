@@ -90,6 +90,7 @@ function zstdgpu_batch_nBlocks(batch: pzstdgpu_batch): LongWord; cdecl; external
 function zstdgpu_batch_srcBytes(batch: pzstdgpu_batch): QWord; cdecl; external ZSTDGPU_LIB;
 function zstdgpu_batch_scratchBytes(batch: pzstdgpu_batch): QWord; cdecl; external ZSTDGPU_LIB;
 function zstdgpu_batch_descriptorDigest(batch: pzstdgpu_batch): QWord; cdecl; external ZSTDGPU_LIB;
+function zstdgpu_batch_kernelVariants(batch: pzstdgpu_batch): LongWord; cdecl; external ZSTDGPU_LIB;   { bit 0 / bit 1: shared sequence tables / Huffman table }
 procedure zstdgpu_batch_set_profiling(batch: pzstdgpu_batch; enabled: LongInt); cdecl; external ZSTDGPU_LIB;
 function zstdgpu_batch_stage_ms(batch: pzstdgpu_batch; ms: PSingle): PtrUInt; cdecl; external ZSTDGPU_LIB;
 function zstdgpu_stage_kernel_name(stage: LongInt): PChar; cdecl; external ZSTDGPU_LIB;

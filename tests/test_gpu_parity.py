@@ -177,6 +177,46 @@ def test_batch_with_dictionary(dctx):
     dd.close()
 
 
+def test_batch_of_dictionary_records_takes_the_shared_table_kernels(dctx):
+    """A batch whose every block takes its Huffman and sequence tables from the dictionary (small records) is decoded by
+    the kernel variants that keep one copy of the dictionary's tables per workgroup; valid records and records with a
+    damaged payload byte (headers intact, so the batch still qualifies), verdicts and bytes as the oracle's."""
+    d = read_dict("dict16k")
+    dd = api.DDict(dctx, d)
+    recs = [e for e in FRAMES if e.get("dict") == "dict16k" and e["name"].startswith("rec") and e["capacity"] == 4096 and "error" not in e]
+    assert len(recs) >= 20
+    frames, caps = [], []
+    rng = np.random.default_rng(9)
+    for rep in range(12):                       # 12 x 25 records: more than one workgroup of either kernel
+        for e in recs:
+            fr = bytearray(read_frame(e))
+            if rep % 3 == 2:                    # damage somewhere in the second half: block payload, not the headers
+                fr[int(rng.integers(len(fr) // 2, len(fr)))] ^= int(rng.integers(1, 256))
+            frames.append(bytes(fr)); caps.append(e["capacity"])
+    import torch
+    src, fin, dst_bytes = api.pack_frames(frames, caps)
+    d_src = torch.from_numpy(src).cuda()
+    d_dst = torch.zeros(dst_bytes, dtype=torch.uint8, device="cuda")
+    for via in (False, True):
+        b = api.Batch(dctx, None, fin, dd, dev_src_ptr=d_src.data_ptr(), dev_src_bytes=src.nbytes) if via else api.Batch(dctx, src, fin, dd)
+        assert api.lib().zstdgpu_batch_kernelVariants(b.h) == 3
+        d_dst.zero_()
+        b.decode(d_src.data_ptr(), d_dst.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        st = b.status().copy()
+        out = d_dst.cpu().numpy()
+        b.close()
+        nbad = 0
+        for i, fr in enumerate(frames):
+            want, werr = oracle.decompress(fr, caps[i], d)
+            assert int(st[i]["errorCode"]) == werr, (via, i)
+            nbad += werr != 0
+            if not werr:
+                o = int(fin[i]["dstOff"])
+                assert int(st[i]["regenSize"]) == len(want) and out[o:o + len(want)].tobytes() == want, (via, i)
+        assert 0 < nbad < len(frames)
+    dd.close()
+
+
 def test_batch_checksum_value(dctx):
     entries = [e for e in FRAMES if e["name"] in ("text128k_l19_c1", "bin512k_l3_c1", "empty_c1", "text33_l3_c1")]
     b, d_src, fin, st, out = run_batch(dctx, entries)

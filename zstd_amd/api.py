@@ -72,7 +72,7 @@ EXPORTS = (
     "zstdgpu_batch_scratchBytes", "zstdgpu_batch_set_profiling", "zstdgpu_batch_stage_ms", "zstdgpu_stage_kernel_name",
     "zstdgpu_decode_frames_noalloc",
     "zstdgpu_xxh64Batch", "zstdgpu_predefinedTables", "zstdgpu_batch_blockInfo", "zstdgpu_batch_copyLiterals", "zstdgpu_batch_copySequences",
-    "zstdgpu_test_setExecuteKernel",
+    "zstdgpu_test_setExecuteKernel", "zstdgpu_batch_kernelVariants",
 )
 
 
@@ -164,6 +164,7 @@ def lib():
     proto("zstdgpu_batch_copyLiterals", sz, vp, vp, u32, vp, sz)
     proto("zstdgpu_batch_copySequences", sz, vp, u32, vp, sz)
     proto("zstdgpu_test_setExecuteKernel", sz, vp, ci)
+    proto("zstdgpu_batch_kernelVariants", u32, vp)
     _lib = L
     return L
 

@@ -813,6 +813,11 @@ extern "C" uint64_t zstdgpu_batch_descriptorDigest(zstdgpu_batch* b)
     return h;
 }
 
+extern "C" uint32_t zstdgpu_batch_kernelVariants(const zstdgpu_batch* b)
+{
+    return b ? (b->seqTablesFromDict ? 1u : 0u) | (b->litDictSingleStream ? 2u : 0u) : 0u;
+}
+
 extern "C" void zstdgpu_batch_destroy(zstdgpu_batch* b)
 {
     if (!b) return;
