@@ -272,6 +272,9 @@ def test_predefined_tables_equal_the_reference_constants(dctx):
 def test_xxh64_stage(dctx):
     rng = np.random.default_rng(5)
     lens = list(range(0, 70)) + [127, 128, 129, 1000, 4095, 4096, 4097, 131072, 1 << 20]
+    # around the multiples of the kernel's read-ahead (8, 16 or 32 stripes of 32 bytes), where its loops hand over
+    for stripes in (7, 8, 9, 15, 16, 17, 18, 31, 32, 33, 34, 47, 48, 49, 63, 64, 65, 66, 95, 96, 97, 128, 129, 2048, 2049):
+        lens += [32 * stripes - 1, 32 * stripes, 32 * stripes + 1, 32 * stripes + 13]
     blob = rng.integers(0, 256, size=sum(lens) + 8, dtype=np.uint8)
     offs = np.cumsum([0] + lens[:-1])
     d = dev(blob)

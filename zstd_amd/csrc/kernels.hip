@@ -3579,35 +3579,78 @@ DEVI uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
 DEVI uint64_t xxh_round(uint64_t acc, uint64_t in) { acc += in * P2; acc = rotl64(acc, 31); return acc * P1; }
 DEVI uint64_t xxh_merge(uint64_t acc, uint64_t v) { v = xxh_round(0, v); acc ^= v; return acc * P1 + P4; }
 
-// XXH64 of [p, p+len) with seed 0, computed by a group of 4 consecutive lanes (one accumulator each);
-// the result is valid on the group's first lane (xxhash.pas:409-488).
-DEVI uint64_t xxh64_group4(const uint8_t* p, uint64_t len, uint32_t gl, uint32_t lead)
+// XXH64 of [p, p+len) with seed 0, computed by a group of 8 consecutive lanes (half a DPP row); the result is valid
+// on the group's first lane (xxhash.pas:409-488).  A round is acc = rotl(acc + in*P2, 31) * P1: two 64-bit multiplies,
+// which are most of its issue time, and only the second depends on the round before.  So the group's lanes 0..3 carry
+// the four accumulators and lanes 7..4 prepare in*P2 of the following stripe for them; both do it with the same
+// multiply instruction (their own factor in K), and the product crosses over through a half-row mirror, which pairs
+// lane w with lane 7-w.  After step t a carrying lane holds the accumulator after t+1 rounds, a preparing lane in*P2 of
+// stripe t+1.
+#ifndef ZG_XXH_DEPTH
+#define ZG_XXH_DEPTH 16
+#endif
+constexpr int kXxhDepth = ZG_XXH_DEPTH;        // stripes requested ahead of the one being folded in
+// y + mirror(y): the two halves of a 64-bit addition with the cross-lane read folded into the additions themselves
+// (the two wait states are what a DPP read of a register the instruction before wrote needs)
+DEVI uint64_t add_half_mirror64(uint64_t y)
+{
+    uint32_t const yl = (uint32_t)y, yh = (uint32_t)(y >> 32);
+    uint32_t lo, hi;
+    asm volatile("s_nop 1\n\t"
+                 "v_add_co_u32_dpp %0, vcc, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "v_addc_co_u32_dpp %1, vcc, %3, %3, vcc row_half_mirror row_mask:0xf bank_mask:0xf"
+                 : "=&v"(lo), "=&v"(hi) : "v"(yl), "v"(yh) : "vcc");
+    return ((uint64_t)hi << 32) | lo;
+}
+// (the choice between the two roles as a bit select: written as a conditional it becomes a branch around the addition)
+#define XXH_STEP(IN) { uint64_t const a_ = add_half_mirror64(y);                                                           \
+                       uint32_t const al_ = (uint32_t)a_, ah_ = (uint32_t)(a_ >> 32);                                      \
+                       uint32_t const xl_ = __builtin_amdgcn_alignbit(al_, ah_, 1), xh_ = __builtin_amdgcn_alignbit(ah_, al_, 1); \
+                       uint32_t const il_ = (uint32_t)(IN), ih_ = (uint32_t)((IN) >> 32);                                  \
+                       y = (((uint64_t)((ih_ & role) | (xh_ & ~role)) << 32) | ((il_ & role) | (xl_ & ~role))) * K; }
+#define XXH_LOAD(BUF, FIRST) _Pragma("unroll") for (int k = 0; k < kXxhDepth; k++) BUF[k] = ld_u64(q + 32 * ((FIRST) + k));
+#define XXH_FOLD(BUF) _Pragma("unroll") for (int k = 0; k < kXxhDepth; k++) XXH_STEP(BUF[k]);
+
+DEVI uint64_t xxh64_group8(const uint8_t* p, uint64_t len, uint32_t gl, uint32_t lead)
 {
     uint64_t h;
     uint64_t const stripes = len / 32;
-    uint64_t v = gl == 0 ? P1 + P2 : gl == 1 ? P2 : gl == 2 ? 0 : 0 - P1;
-    const uint8_t* q = p + 8 * gl;
-    // The rounds of a lane depend on one another, so what a wave can hide of the memory latency is what it requests ahead:
-    // eight stripes are in flight while the eight before them are folded in.
-    uint64_t s = 0;
-    if (stripes >= 8) {
-        uint64_t cur[8], nxt[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) cur[k] = ld_u64(q + 32 * k);
-        q += 256;
-        for (s = 8; s + 8 <= stripes; s += 8, q += 256) {
-#pragma unroll
-            for (int k = 0; k < 8; k++) nxt[k] = ld_u64(q + 32 * k);
-#pragma unroll
-            for (int k = 0; k < 8; k++) v = xxh_round(v, cur[k]);
-#pragma unroll
-            for (int k = 0; k < 8; k++) cur[k] = nxt[k];
+    bool const prep = gl >= 4;
+    uint32_t const w = prep ? 7 - gl : gl;                  // which of the stripe's four words this lane works on
+    uint64_t const K = prep ? P2 : P1;
+    uint32_t const role = prep ? ~0u : 0u;
+    const uint8_t* const q = p + 8 * w;
+    uint64_t y = w == 0 ? P1 + P2 : w == 1 ? P2 : w == 2 ? 0 : 0 - P1;
+    if (stripes) {
+        if (prep) y = ld_u64(q) * P2;
+        uint64_t s = 0;                                     // steps done; step t takes the word of stripe t+1
+        // The steps of a lane depend on one another, so what a wave can hide of the memory latency is what it requests
+        // ahead: kXxhDepth stripes are in flight while the kXxhDepth before them are folded in.
+        if (s + kXxhDepth < stripes) {
+            uint64_t bufA[kXxhDepth], bufB[kXxhDepth];          // (two buffers taking turns, so that no step pays for a register copy)
+            XXH_LOAD(bufA, s + 1)
+            for (;;) {
+                if (!(s + 2 * kXxhDepth < stripes)) { XXH_FOLD(bufA) s += kXxhDepth; break; }
+                XXH_LOAD(bufB, s + kXxhDepth + 1)
+                XXH_FOLD(bufA)
+                s += kXxhDepth;
+                if (!(s + 2 * kXxhDepth < stripes)) { XXH_FOLD(bufB) s += kXxhDepth; break; }
+                XXH_LOAD(bufA, s + kXxhDepth + 1)
+                XXH_FOLD(bufB)
+                s += kXxhDepth;
+            }
         }
+        // 1..kXxhDepth steps are left; a word past the last stripe is read from the last stripe instead (its product is not used)
+        {
+            uint64_t t[kXxhDepth];
+            uint64_t const last = stripes - 1;
 #pragma unroll
-        for (int k = 0; k < 8; k++) v = xxh_round(v, cur[k]);
+            for (int k = 0; k < kXxhDepth; k++) { uint64_t const i = s + 1 + k; t[k] = ld_u64(q + 32 * (i < last ? i : last)); }
+#pragma unroll
+            for (int k = 0; k < kXxhDepth; k++) if (s + k < stripes) XXH_STEP(t[k]);
+        }
     }
-    for (; s < stripes; s++, q += 32) v = xxh_round(v, ld_u64(q));
-    uint64_t const v1 = __shfl(v, lead), v2 = __shfl(v, lead + 1), v3 = __shfl(v, lead + 2), v4 = __shfl(v, lead + 3);
+    uint64_t const v1 = __shfl(y, lead), v2 = __shfl(y, lead + 1), v3 = __shfl(y, lead + 2), v4 = __shfl(y, lead + 3);
     if (len >= 32) {
         h = rotl64(v1, 1) + rotl64(v2, 7) + rotl64(v3, 12) + rotl64(v4, 18);
         h = xxh_merge(h, v1); h = xxh_merge(h, v2); h = xxh_merge(h, v3); h = xxh_merge(h, v4);
@@ -3617,18 +3660,21 @@ DEVI uint64_t xxh64_group4(const uint8_t* p, uint64_t len, uint32_t gl, uint32_t
     const uint8_t* const end = p + len;
     if (gl == 0) {
         while (t + 8 <= end) { h ^= xxh_round(0, ld_u64(t)); h = rotl64(h, 27) * P1 + P4; t += 8; }
-        if (t + 4 <= end) { uint32_t w; __builtin_memcpy(&w, t, 4); h ^= (uint64_t)w * P1; h = rotl64(h, 23) * P2 + P3; t += 4; }
+        if (t + 4 <= end) { uint32_t w4; __builtin_memcpy(&w4, t, 4); h ^= (uint64_t)w4 * P1; h = rotl64(h, 23) * P2 + P3; t += 4; }
         while (t < end) { h ^= (uint64_t)(*t) * P5; h = rotl64(h, 11) * P1; t++; }
         h ^= h >> 33; h *= P2; h ^= h >> 29; h *= P3; h ^= h >> 32;
     }
     return h;
 }
+#undef XXH_STEP
+#undef XXH_LOAD
+#undef XXH_FOLD
 
 __global__ __launch_bounds__(64) void k_checksum(BatchParams p)
 {
     uint32_t const lane = threadIdx.x;
-    uint32_t const gl = lane & 3, lead = lane & ~3u;
-    uint32_t const fi = blockIdx.x * 16 + (lane >> 2);
+    uint32_t const gl = lane & 7, lead = lane & ~7u;
+    uint32_t const fi = blockIdx.x * 8 + (lane >> 3);
     if (fi >= p.nFrames) return;
     DevFrame const f = p.frames[fi];
     DevFrameStatus* const fs = p.status + fi;
@@ -3638,7 +3684,7 @@ __global__ __launch_bounds__(64) void k_checksum(BatchParams p)
     if (!err && f.contentSize != ~0ull && regen != f.contentSize) err = E_corruption;
     bool const doSum = !err && f.checksumFlag != 0;
     uint64_t h = 0;
-    if (doSum && f.checksumFlag == 1) h = xxh64_group4(p.dst + f.dstOff, regen, gl, lead);
+    if (doSum && f.checksumFlag == 1) h = xxh64_group8(p.dst + f.dstOff, regen, gl, lead);
     if (gl == 0) {
         if (doSum) {
             if (f.checksumFlag == 2) err = E_checksum_wrong;          // trailer missing from the source
@@ -3651,10 +3697,10 @@ __global__ __launch_bounds__(64) void k_checksum(BatchParams p)
 __global__ __launch_bounds__(64) void k_xxh64(const uint8_t* base, const uint64_t* off, const uint64_t* len, uint32_t n, uint64_t* out)
 {
     uint32_t const lane = threadIdx.x;
-    uint32_t const gl = lane & 3, lead = lane & ~3u;
-    uint32_t const i = blockIdx.x * 16 + (lane >> 2);
+    uint32_t const gl = lane & 7, lead = lane & ~7u;
+    uint32_t const i = blockIdx.x * 8 + (lane >> 3);
     if (i >= n) return;
-    uint64_t const h = xxh64_group4(base + off[i], len[i], gl, lead);
+    uint64_t const h = xxh64_group8(base + off[i], len[i], gl, lead);
     if (gl == 0) out[i] = h;
 }
 
@@ -3766,7 +3812,7 @@ void launch_execute(const BatchParams& pIn, void* stream)
 void launch_checksum(const BatchParams& p, void* stream)
 {
     if (!p.nFrames) return;
-    hipLaunchKernelGGL(k_checksum, dim3((p.nFrames + 15) / 16), dim3(64), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(k_checksum, dim3((p.nFrames + 7) / 8), dim3(64), 0, (hipStream_t)stream, p);
 }
 void launch_digest_dict(const uint8_t* devDict, uint32_t dictSize, DevDict* out, void* stream)
 {
@@ -3786,7 +3832,7 @@ void launch_zero(void* p, size_t bytes, void* stream)
 void launch_xxh64(const uint8_t* base, const uint64_t* off, const uint64_t* len, uint32_t n, uint64_t* out, void* stream)
 {
     if (!n) return;
-    hipLaunchKernelGGL(k_xxh64, dim3((n + 15) / 16), dim3(64), 0, (hipStream_t)stream, base, off, len, n, out);
+    hipLaunchKernelGGL(k_xxh64, dim3((n + 7) / 8), dim3(64), 0, (hipStream_t)stream, base, off, len, n, out);
 }
 
 }  // namespace zg
