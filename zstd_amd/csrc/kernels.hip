@@ -1447,8 +1447,9 @@ DEVI uint32_t dev_parse_desc(int t, uint32_t type, SrcT src, uint32_t avail, Cel
 //   3. each lane counts the symbols in its 16th of the table (rank of every cell inside the chunk), the counts
 //      are prefix-summed per symbol over the lanes, and every cell gets nextState = norm + cells of its symbol
 //      before it.
-// scratch: cum u16[64] | occ u8[512] | cnt u16[16][64]  (2688 bytes)
-constexpr uint32_t kGrpBuildScratch = 128 + 512 + 2048;
+// scratch: cum u16[64] | occ u8[512] | cnt u16[16][56]  (2432 bytes; symbols go up to 52)
+constexpr uint32_t kCntStride = 56;
+constexpr uint32_t kGrpBuildScratch = 128 + 512 + 16 * 2 * kCntStride;
 DEVI void grp_build_seq_table(int t, uint32_t* cells, const int16_t* norm, uint32_t maxSV, uint32_t tableLog, uint8_t* scratch, uint32_t gl,
                               const uint8_t* llBits, const uint8_t* mlBits)
 {
@@ -1503,14 +1504,14 @@ DEVI void grp_build_seq_table(int t, uint32_t* cells, const int16_t* norm, uint3
             }
         }
     }
-    for (uint32_t q = 0; q < 8; q++) *(uint4*)(cnt + 64 * gl + 8 * q) = make_uint4(0, 0, 0, 0);
+    for (uint32_t q = 0; q < kCntStride / 8; q++) *(uint4*)(cnt + kCntStride * gl + 8 * q) = make_uint4(0, 0, 0, 0);
     lds_sync();
     for (uint32_t g = 0; g < C; g += 8) {
         uint32_t sym[8], c[8];
 #pragma unroll
         for (int j = 0; j < 8; j++) sym[j] = cells[i0 + (g + j < C ? g + j : 0u)];
 #pragma unroll
-        for (int j = 0; j < 8; j++) c[j] = cnt[64 * gl + sym[j]];
+        for (int j = 0; j < 8; j++) c[j] = cnt[kCntStride * gl + sym[j]];
         // occurrences of the same symbol earlier in this batch
 #pragma unroll
         for (int j = 1; j < 8; j++) {
@@ -1520,7 +1521,7 @@ DEVI void grp_build_seq_table(int t, uint32_t* cells, const int16_t* norm, uint3
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             if (g + j < C) {
-                cnt[64 * gl + sym[j]] = (uint16_t)(c[j] + 1);      // (in order: the last occurrence leaves the final count)
+                cnt[kCntStride * gl + sym[j]] = (uint16_t)(c[j] + 1);      // (in order: the last occurrence leaves the final count)
                 cells[i0 + g + j] = sym[j] | (c[j] << 8);
             }
         }
@@ -1531,9 +1532,9 @@ DEVI void grp_build_seq_table(int t, uint32_t* cells, const int16_t* norm, uint3
         uint32_t run = n == -1 ? 1u : (uint32_t)n;
         uint32_t c[16];
 #pragma unroll
-        for (int l = 0; l < 16; l++) c[l] = cnt[64 * l + s];
+        for (int l = 0; l < 16; l++) c[l] = cnt[kCntStride * l + s];
 #pragma unroll
-        for (int l = 0; l < 16; l++) { cnt[64 * l + s] = (uint16_t)run; run += c[l]; }
+        for (int l = 0; l < 16; l++) { cnt[kCntStride * l + s] = (uint16_t)run; run += c[l]; }
     }
     lds_sync();
     for (uint32_t g = 0; g < C; g += 8) {
@@ -1543,7 +1544,7 @@ DEVI void grp_build_seq_table(int t, uint32_t* cells, const int16_t* norm, uint3
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             uint32_t const sym = v[j] & 255u;
-            k[j] = cnt[64 * gl + sym];
+            k[j] = cnt[kCntStride * gl + sym];
             ab[j] = t == T_LL ? llBits[sym] : t == T_OF ? sym : mlBits[sym];
         }
 #pragma unroll
@@ -1617,7 +1618,10 @@ constexpr int kSeqThreads = 64 * (kChainWaves + 4);   // chain waves: the serial
 constexpr uint32_t kSeqRound = 64;          // sequences per round
 constexpr uint32_t kWinUnits = 128;         // circular window of the bitstream, 16-byte units (+ 1 mirror unit)
 constexpr uint32_t kWinAhead = 80;          // units kept loaded below the cursor of the round before last
-constexpr uint32_t kSeqJobWords = 512 + 512 + 256 + 4 * (kWinUnits + 1) + 2 * 4 * kSeqRound;   // LL | ML | OF cells, window, two record rings
+constexpr uint32_t kSeqJobWords = 512 + 512 + 256 + 4 * (kWinUnits + 1) + 2 * 2 * kSeqRound;   // LL | ML | OF cells, window, two rings of chain notes
+// A chain note is 8 bytes per sequence, 16 bits from each of a block's four chain lanes: the LL, ML and OF states the
+// sequence was decoded from (the helpers read the cells again) and the low 16 bits of the cursor before it (a round moves
+// the cursor by 64 x 89 bits at most, so the helpers can complete it from the cursor at the start of the round).
 constexpr uint32_t kRepIdxShift = 29;
 
 DEVI uint32_t rep_resolve(uint32_t x, const uint32_t* repIn)
@@ -1776,7 +1780,7 @@ __global__ __launch_bounds__(kDictTables ? kSeqLaunchThreadsDict : kSeqThreads) 
             int16_t* const norm = (int16_t*)(scr + 256);           // 64 counts
             uint32_t* const note = (uint32_t*)(scr + 384);         // {kind, maxSV, log, consumed} from the first lane
             uint8_t* const bscr = scr + 512;                       // grp_build_seq_table scratch
-            static_assert(512 + kGrpBuildScratch <= 4 * (4 * (kWinUnits + 1) + 2 * 4 * kSeqRound), "table scratch fits");
+            static_assert(512 + kGrpBuildScratch <= 4 * (4 * (kWinUnits + 1) + 2 * 2 * kSeqRound), "table scratch fits");
             uint32_t const hdrAvail = off < blk.cSize ? blk.cSize - off : 0;
             uint32_t const nStaged = hdrAvail < 256 ? hdrAvail : 256;
             if (!kDictTables) {
@@ -1902,7 +1906,7 @@ __global__ __launch_bounds__(kDictTables ? kSeqLaunchThreadsDict : kSeqThreads) 
     uint32_t remaining = 0;
     int dryBelow = 0;                          // a cursor below this is past the stream start by more than the last state update may read
     typedef const __attribute__((address_space(3))) uint32_t* lds_u32;
-    typedef __attribute__((address_space(3))) uint32_t* lds_u32w;
+    typedef __attribute__((address_space(3))) uint16_t* lds_u16w;
     uint32_t const tabL = (uint32_t)(uintptr_t)(lds_u32)(role == 0 ? tLL : role == 1 ? tML : role == 2 ? tOF : &zeroCell);    // LDS byte address of this lane's table
     if (chainLane) {
         SeqCtl const c = ctl[slot];
@@ -1946,14 +1950,14 @@ __global__ __launch_bounds__(kDictTables ? kSeqLaunchThreadsDict : kSeqThreads) 
             // ---- the serial chains, round k
             if (act && chainLane) {
                 uint32_t n = 0;
-                uint32_t* const ring = ring0 + par * 4 * kSeqRound;
+                uint32_t* const ring = ring0 + par * 2 * kSeqRound;
                 if (remaining) {
                     // lowest bit the window is known to hold, plus what 8 sequences and a 96-bit peek can reach (as a bound on
                     // T = cursor - 95, the variable the loop carries)
                     uint32_t const Tlim = ((e2 >> 7) - kWinAhead) * 128 + 96 + 8 * 89 - 95;
                     uint32_t i = 0;
                     uint32_t winL = (uint32_t)(uintptr_t)(lds_u32)win;     // LDS byte addresses, opaque to the compiler: keeps the
-                    uint32_t ringL = (uint32_t)(uintptr_t)(lds_u32)ring + 4 * role;    // accesses at small immediate offsets of one address
+                    uint32_t ringL = (uint32_t)(uintptr_t)(lds_u32)ring + 2 * role;    // accesses at small immediate offsets of one address
                     asm volatile("" : "+v"(winL), "+v"(ringL));
                     // Software pipeline: the cell of the next sequence is requested as soon as its state is known, and the
                     // bookkeeping (ring entry, cursor, window request for the next sequence) runs while that read is in flight.
@@ -1965,6 +1969,7 @@ __global__ __launch_bounds__(kDictTables ? kSeqLaunchThreadsDict : kSeqThreads) 
                     };
                     // 96 bits below the cursor (top at Q + 1, so that the state bits of any sequence start inside them)
                     uint32_t T = Q - 95, a0, a1, a2, a3;
+                    uint32_t const Tround = T;
                     win_read(T, a0, a1, a2, a3);
                     uint32_t c = *(lds_u32)(uintptr_t)(tabL + 4 * st);
 #ifdef ZG_STAMPS
@@ -1984,6 +1989,7 @@ __global__ __launch_bounds__(kDictTables ? kSeqLaunchThreadsDict : kSeqThreads) 
                             asm volatile("" : "+v"(S));
                             S += quad_perm<0x4E>(S);                    // lanes 2 3 0 1
                             // state bits, order LL, ML, OF (:1220-1225): this lane's lie under those of the tables before it
+                            uint32_t const stPrev = st;
                             uint32_t const nb = cell_nbBits(c);
                             uint32_t const ng = __builtin_amdgcn_ubfe(c, 14, 5);
                             uint32_t const o = ng + (quad_perm<0x90>(ng) & mask1) + (quad_perm<0x40>(ng) & mask2);   // + the lane below, + two lanes below; mod 32
@@ -2002,18 +2008,18 @@ __global__ __launch_bounds__(kDictTables ? kSeqLaunchThreadsDict : kSeqThreads) 
                             asm volatile("" : "+v"(Tm));            // (one three-operand add)
                             T = Tm - __builtin_amdgcn_ubfe(S, 21, 5);
                             win_read(T, a0, a1, a2, a3);
-                            *(lds_u32w)(uintptr_t)(ringP + 16 * j) = role == 3 ? Tprev : c;
+                            *(lds_u16w)(uintptr_t)(ringP + 8 * j) = (uint16_t)(role == 3 ? Tprev : stPrev);
                             c = cn;
                             __builtin_amdgcn_sched_barrier(0);
                         }
-                        ringP += 16 * 8;
+                        ringP += 8 * 8;
                         asm volatile("" : "+v"(ringP));
                     }
 #ifdef ZG_STAMPS
                     kLoop += __builtin_readcyclecounter() - kl0; kRounds++;
 #endif
                     n = i < remaining ? i : remaining;
-                    Q = (n < i ? ring[4 * n + 3] : T) + 95;
+                    Q = (n < i ? Tround - ((Tround - (ring[2 * n + 1] >> 16)) & 0xFFFFu) : T) + 95;
                     remaining -= n;
                     // the stream ran dry: some sequence of this round is flagged by the helpers, nothing after it counts
                     if ((int)Q < dryBelow) remaining = 0;
@@ -2029,10 +2035,11 @@ __global__ __launch_bounds__(kDictTables ? kSeqLaunchThreadsDict : kSeqThreads) 
             uint32_t const hp = par ^ 1;
             uint2 const pb = pub[hp][slot];
             uint32_t const n = pb.y;
-            const uint32_t* const ring = ring0 + hp * 4 * kSeqRound;
+            const uint32_t* const ring = ring0 + hp * 2 * kSeqRound;
             if (n) {
                 uint32_t const base = seqDone;
                 bool const more = base + n < nbSeq;
+                uint32_t const Tref = Qend - 95;      // at or above every cursor note of the round, by less than 2^16
                 // units the chain may need two rounds from now: down to (cursor after this round) - 80 units
                 Qend = pb.x;
                 uint32_t const newFrom = (Qend >> 7) - kWinAhead;     // <= loadedFrom; at most 46 units below it
@@ -2046,8 +2053,10 @@ __global__ __launch_bounds__(kDictTables ? kSeqLaunchThreadsDict : kSeqThreads) 
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     uint32_t const i = 4 * gl + u;
-                    uint4 const r = *(const uint4*)(ring + 4 * i);
-                    uint32_t const cLL = r.x, cML = r.y, cOF = r.z, Qs = r.w + 95;
+                    uint2 const r = *(const uint2*)(ring + 2 * i);
+                    // (masked: the notes of lanes past the round's last sequence may be anything)
+                    uint32_t const cLL = tLL[r.x & 0x1FFu], cML = tML[__builtin_amdgcn_ubfe(r.x, 16, 9)], cOF = tOF[r.y & 0xFFu];
+                    uint32_t const Qs = Tref - ((Tref - (r.y >> 16)) & 0xFFFFu) + 95;
                     bool const valid = i < n;
                     uint32_t tHi, tLo;
                     peek64c(win, Qs, tHi, tLo);
@@ -2630,6 +2639,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
     static_assert((65 + 4 * 64) * 4 <= 64 * 32, "the sequence table fits in the match stage");
     uint32_t const lane = threadIdx.x;
     uint32_t const fi = blockIdx.x;
+#ifdef ZG_X_LDSPAD    // experiment: LDS the kernel does not use, to hold fewer waves on a compute unit
+    __shared__ uint32_t ldsPad[ZG_X_LDSPAD / 4];
+    asm volatile("" :: "v"((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint32_t*)&ldsPad[lane]));
+#endif
     DevFrame const f = p.frames[fi];
     DevFrameStatus* const fs = p.status + fi;
     if (fs->errorCode) return;   // host error or unusable dictionary (set by k_layout)
