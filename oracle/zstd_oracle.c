@@ -1648,3 +1648,256 @@ size_t oracle_decompress_batch(BYTE* dstBase, const U64* dstOff, const U64* dstC
     }
     return total;
 }
+
+/* ===================== bufferless streaming decode (zstd_decompressf.pas:995-1246, :1386-1452) =====================
+ * ZSTD_decompressBegin / ZSTD_decompressBegin_usingDict, ZSTD_nextSrcSizeToDecompress, ZSTD_nextInputType and
+ * ZSTD_decompressContinue: the caller hands over exactly the bytes the context asks for, one frame header, block header,
+ * block or checksum at a time, and every block is decoded straight into the caller's buffer, whose earlier output is the
+ * window.  As everywhere in this file the arithmetic is that of zstd 1.4.8, which the port transliterates (the port's
+ * ZSTD_decodeFrameHeader, :541-555, lacks the dictionary ID check of 1.4.8; it is kept here). */
+typedef enum { ZSTDds_getFrameHeaderSize = 0, ZSTDds_decodeFrameHeader, ZSTDds_decodeBlockHeader, ZSTDds_decompressBlock,
+               ZSTDds_decompressLastBlock, ZSTDds_checkChecksum, ZSTDds_decodeSkippableHeader, ZSTDds_skipFrame } ZSTD_dStage;   /* zstd_ddict.pas:96-100 */
+/* xxhash.pas:533-545, :686-757, :759-828: the streaming form of XXH64 */
+typedef struct { U64 total_len, v1, v2, v3, v4; BYTE mem64[32]; U32 memsize; } XXH64_state_t;
+static void XXH64_reset(XXH64_state_t* s, U64 seed)
+{
+    memset(s, 0, sizeof(*s));
+    s->v1 = seed + P64_1 + P64_2; s->v2 = seed + P64_2; s->v3 = seed + 0; s->v4 = seed - P64_1;
+}
+static void XXH64_update(XXH64_state_t* s, const BYTE* p, size_t len)
+{
+    const BYTE* const bEnd = p + len;
+    s->total_len += len;
+    if (s->memsize + len < 32) { if (len) memcpy(s->mem64 + s->memsize, p, len); s->memsize += (U32)len; return; }
+    if (s->memsize) {
+        memcpy(s->mem64 + s->memsize, p, 32 - s->memsize);
+        s->v1 = XXH64_round(s->v1, rdLE64(s->mem64)); s->v2 = XXH64_round(s->v2, rdLE64(s->mem64 + 8));
+        s->v3 = XXH64_round(s->v3, rdLE64(s->mem64 + 16)); s->v4 = XXH64_round(s->v4, rdLE64(s->mem64 + 24));
+        p += 32 - s->memsize; s->memsize = 0;
+    }
+    while (p + 32 <= bEnd) {
+        s->v1 = XXH64_round(s->v1, rdLE64(p)); s->v2 = XXH64_round(s->v2, rdLE64(p + 8));
+        s->v3 = XXH64_round(s->v3, rdLE64(p + 16)); s->v4 = XXH64_round(s->v4, rdLE64(p + 24));
+        p += 32;
+    }
+    if (p < bEnd) { memcpy(s->mem64, p, (size_t)(bEnd - p)); s->memsize = (U32)(bEnd - p); }
+}
+static U64 XXH64_digest(const XXH64_state_t* s)
+{
+    const BYTE* p = s->mem64;
+    const BYTE* const bEnd = p + s->memsize;
+    U64 h64;
+    if (s->total_len >= 32) {
+        h64 = rotl64(s->v1, 1) + rotl64(s->v2, 7) + rotl64(s->v3, 12) + rotl64(s->v4, 18);
+        h64 = XXH64_mergeRound(h64, s->v1); h64 = XXH64_mergeRound(h64, s->v2);
+        h64 = XXH64_mergeRound(h64, s->v3); h64 = XXH64_mergeRound(h64, s->v4);
+    } else h64 = s->v3 + P64_5;
+    h64 += s->total_len;
+    while (p + 8 <= bEnd) { U64 const k1 = XXH64_round(0, rdLE64(p)); h64 ^= k1; h64 = rotl64(h64, 27) * P64_1 + P64_4; p += 8; }
+    if (p + 4 <= bEnd) { h64 ^= (U64)rdLE32(p) * P64_1; h64 = rotl64(h64, 23) * P64_2 + P64_3; p += 4; }
+    while (p < bEnd) { h64 ^= (*p) * P64_5; h64 = rotl64(h64, 11) * P64_1; p++; }
+    h64 ^= h64 >> 33; h64 *= P64_2; h64 ^= h64 >> 29; h64 *= P64_3; h64 ^= h64 >> 32;
+    return h64;
+}
+
+typedef struct {
+    DCtx d;
+    ZSTD_dStage stage;
+    size_t expected, headerSize, rleSize;
+    BYTE headerBuffer[18];                  /* ZSTD_FRAMEHEADERSIZE_MAX */
+    FrameHeader fParams;
+    U32 bType, validateChecksum;
+    U64 decodedSize;
+    XXH64_state_t xxhState;
+    const BYTE* previousDstEnd;
+    BYTE* dictCopy;                         /* the dictionary must outlive the frame (ZSTD_refDictContent keeps a pointer): a copy owned here */
+} CDCtx;
+
+void* oracle_createDCtx(void) { oracle_init(); return calloc(1, sizeof(CDCtx)); }
+void oracle_freeDCtx(void* c) { if (c) { free(((CDCtx*)c)->dictCopy); free(c); } }
+/* ZSTD_DCtx_setParameter for the two parameters that reach this path (zstd_decompressf.pas:1763-1807) */
+void oracle_DCtx_setFormat(void* c, unsigned magicless, unsigned forceIgnoreChecksum)
+{ ((CDCtx*)c)->d.magicless = magicless != 0; ((CDCtx*)c)->d.forceIgnoreChecksum = forceIgnoreChecksum != 0; }
+
+/* zstd_decompressf.pas:1249-1256 */
+static void ZSTD_refDictContent(CDCtx* c, const BYTE* dict, size_t dictSize)
+{
+    c->d.dictEnd = c->previousDstEnd;
+    c->d.virtualStart = (const BYTE*)((uintptr_t)dict - ((uintptr_t)c->previousDstEnd - (uintptr_t)c->d.prefixStart));
+    c->d.prefixStart = dict;
+    c->previousDstEnd = dict + dictSize;
+}
+/* zstd_decompress_block.pas:1545-1554 */
+static void ZSTD_checkContinuity(CDCtx* c, const BYTE* dst)
+{
+    if (dst != c->previousDstEnd) {   /* not contiguous */
+        c->d.dictEnd = c->previousDstEnd;
+        c->d.virtualStart = (const BYTE*)((uintptr_t)dst - ((uintptr_t)c->previousDstEnd - (uintptr_t)c->d.prefixStart));
+        c->d.prefixStart = dst;
+        c->previousDstEnd = dst;
+    }
+}
+/* zstd_decompressf.pas:1386-1408, :1410-1421 (with :1358-1384) */
+size_t oracle_decompressBegin_usingDict(void* cv, const void* dict, size_t dictSize)
+{
+    CDCtx* const c = (CDCtx*)cv;
+    DCtx* const dctx = &c->d;
+    c->expected = dctx->magicless ? 1 : 5;      /* ZSTD_startingInputLength (:96-107) */
+    c->stage = ZSTDds_getFrameHeaderSize;
+    c->decodedSize = 0;
+    c->previousDstEnd = NULL; dctx->prefixStart = NULL; dctx->virtualStart = NULL; dctx->dictEnd = NULL;
+    dctx->litEntropy = dctx->fseEntropy = 0;
+    dctx->dictID = 0;
+    c->bType = 3;                               /* bt_reserved */
+    dctx->entropy.rep[0] = 1; dctx->entropy.rep[1] = 4; dctx->entropy.rep[2] = 8;
+    dctx->LLTptr = &dctx->entropy.LLTable; dctx->MLTptr = &dctx->entropy.MLTable; dctx->OFTptr = &dctx->entropy.OFTable;
+    dctx->HUFptr = &dctx->entropy.hufTable;
+    free(c->dictCopy); c->dictCopy = NULL;
+    if (dict && dictSize) {
+        const BYTE* content; size_t contentSize = dictSize;
+        c->dictCopy = (BYTE*)malloc(dictSize);
+        if (!c->dictCopy) return ERR(GENERIC);
+        memcpy(c->dictCopy, dict, dictSize);
+        content = c->dictCopy;
+        if (dictSize >= 8 && rdLE32(content) == ZSTD_MAGIC_DICTIONARY) {
+            dctx->dictID = rdLE32(content + 4);
+            {   size_t const eSize = ZSTD_loadDEntropy(&dctx->entropy, content, dictSize);
+                if (isErr(eSize)) return ERR(dictionary_corrupted);
+                content += eSize; contentSize -= eSize; }
+            dctx->litEntropy = dctx->fseEntropy = 1;
+        }
+        ZSTD_refDictContent(c, content, contentSize);
+    }
+    return 0;
+}
+size_t oracle_decompressBegin(void* cv) { return oracle_decompressBegin_usingDict(cv, NULL, 0); }
+/* zstd_decompressf.pas:995-998 */
+size_t oracle_nextSrcSizeToDecompress(void* cv) { return ((CDCtx*)cv)->expected; }
+/* zstd_decompressf.pas:1010-1017: a raw block may be handed over in pieces */
+static size_t ZSTD_nextSrcSizeToDecompressWithInputSize(const CDCtx* c, size_t inputSize)
+{
+    if (!(c->stage == ZSTDds_decompressBlock || c->stage == ZSTDds_decompressLastBlock)) return c->expected;
+    if (c->bType != 0) return c->expected;
+    {   size_t const m = inputSize > 1 ? inputSize : 1;
+        return m < c->expected ? m : c->expected; }
+}
+/* zstd_decompressf.pas:1019-1039: ZSTDnit_frameHeader 0, blockHeader 1, block 2, lastBlock 3, checksum 4, skippableFrame 5 */
+unsigned oracle_nextInputType(void* cv)
+{
+    switch (((CDCtx*)cv)->stage) {
+    default:
+    case ZSTDds_getFrameHeaderSize: case ZSTDds_decodeFrameHeader: return 0;
+    case ZSTDds_decodeBlockHeader: return 1;
+    case ZSTDds_decompressBlock: return 2;
+    case ZSTDds_decompressLastBlock: return 3;
+    case ZSTDds_checkChecksum: return 4;
+    case ZSTDds_decodeSkippableHeader: case ZSTDds_skipFrame: return 5;
+    }
+}
+/* zstd_decompressf.pas:1050-1246 */
+size_t oracle_decompressContinue(void* cv, void* dstv, size_t dstCapacity, const void* srcv, size_t srcSize)
+{
+    CDCtx* const c = (CDCtx*)cv;
+    DCtx* const dctx = &c->d;
+    BYTE* const dst = (BYTE*)dstv;
+    const BYTE* const src = (const BYTE*)srcv;
+    if (srcSize != ZSTD_nextSrcSizeToDecompressWithInputSize(c, srcSize)) return ERR(srcSize_wrong);
+    if (dstCapacity) ZSTD_checkContinuity(c, dst);
+    switch (c->stage) {
+    case ZSTDds_getFrameHeaderSize:
+        if (!dctx->magicless) {
+            if (srcSize < 4) return ERR(srcSize_wrong);      /* (the reference reads the magic number whatever it was given) */
+            if ((rdLE32(src) & ZSTD_MAGIC_SKIPPABLE_MASK) == ZSTD_MAGIC_SKIPPABLE_START) {
+                memcpy(c->headerBuffer, src, srcSize);
+                c->expected = 8 - srcSize;                   /* ZSTD_SKIPPABLEHEADERSIZE */
+                c->stage = ZSTDds_decodeSkippableHeader;
+                return 0;
+            }
+        }
+        c->headerSize = ZSTD_frameHeaderSize(src, srcSize, dctx->magicless);
+        if (isErr(c->headerSize)) return c->headerSize;
+        memcpy(c->headerBuffer, src, srcSize);
+        c->expected = c->headerSize - srcSize;
+        c->stage = ZSTDds_decodeFrameHeader;
+        return 0;
+    case ZSTDds_decodeFrameHeader:
+        memcpy(c->headerBuffer + (c->headerSize - srcSize), src, srcSize);
+        {   /* ZSTD_decodeFrameHeader (:541-555) */
+            size_t const r = ZSTD_getFrameHeader(&c->fParams, c->headerBuffer, c->headerSize, dctx->magicless);
+            if (isErr(r)) return r;
+            if (r > 0) return ERR(srcSize_wrong);
+            if (c->fParams.dictID && (dctx->dictID != c->fParams.dictID)) return ERR(dictionary_wrong);
+            c->validateChecksum = (c->fParams.checksumFlag && !dctx->forceIgnoreChecksum) ? 1 : 0;
+            if (c->validateChecksum) XXH64_reset(&c->xxhState, 0);
+            dctx->windowSize = c->fParams.windowSize;
+        }
+        c->expected = 3;
+        c->stage = ZSTDds_decodeBlockHeader;
+        return 0;
+    case ZSTDds_decodeBlockHeader:
+        {   blockProperties_t bp;
+            size_t const cBlockSize = ZSTD_getcBlockSize(src, 3, &bp);
+            if (isErr(cBlockSize)) return cBlockSize;
+            if (cBlockSize > c->fParams.blockSizeMax) return ERR(corruption_detected);
+            c->expected = cBlockSize;
+            c->bType = bp.blockType;
+            c->rleSize = bp.origSize;
+            if (cBlockSize) { c->stage = bp.lastBlock ? ZSTDds_decompressLastBlock : ZSTDds_decompressBlock; return 0; }
+            if (bp.lastBlock) {      /* empty block */
+                if (c->fParams.checksumFlag) { c->expected = 4; c->stage = ZSTDds_checkChecksum; }
+                else { c->expected = 0; c->stage = ZSTDds_getFrameHeaderSize; }
+            } else { c->expected = 3; c->stage = ZSTDds_decodeBlockHeader; }
+            return 0;
+        }
+    case ZSTDds_decompressLastBlock:
+    case ZSTDds_decompressBlock:
+        {   size_t rSize;
+            switch (c->bType) {
+            case 2: rSize = ZSTD_decompressBlock_internal(dctx, dst, dstCapacity, src, srcSize); c->expected = 0; break;
+            case 0:
+                if (srcSize > dstCapacity) return ERR(dstSize_tooSmall);      /* ZSTD_copyRawBlock (:699-713) */
+                if (srcSize) memcpy(dst, src, srcSize);
+                rSize = srcSize;
+                c->expected -= rSize;
+                break;
+            case 1:
+                if (c->rleSize > dstCapacity) rSize = ERR(dstSize_tooSmall);   /* ZSTD_setRleBlock (:715-731) */
+                else { if (c->rleSize) memset(dst, *src, c->rleSize); rSize = c->rleSize; }
+                c->expected = 0;
+                break;
+            default: return ERR(corruption_detected);
+            }
+            if (isErr(rSize)) return rSize;
+            if (rSize > c->fParams.blockSizeMax) return ERR(corruption_detected);
+            c->decodedSize += rSize;
+            if (c->validateChecksum) XXH64_update(&c->xxhState, dst, rSize);
+            c->previousDstEnd = dst + rSize;
+            if (c->expected > 0) return rSize;      /* the rest of a raw block is still to come */
+            if (c->stage == ZSTDds_decompressLastBlock) {
+                if (c->fParams.frameContentSize != ZSTD_CONTENTSIZE_UNKNOWN && c->decodedSize != c->fParams.frameContentSize) return ERR(corruption_detected);
+                if (c->fParams.checksumFlag) { c->expected = 4; c->stage = ZSTDds_checkChecksum; }
+                else { c->expected = 0; c->stage = ZSTDds_getFrameHeaderSize; }
+            } else { c->stage = ZSTDds_decodeBlockHeader; c->expected = 3; }
+            return rSize;
+        }
+    case ZSTDds_checkChecksum:
+        if (c->validateChecksum) {
+            U32 const h32 = (U32)XXH64_digest(&c->xxhState);
+            if (rdLE32(src) != h32) return ERR(checksum_wrong);
+        }
+        c->expected = 0;
+        c->stage = ZSTDds_getFrameHeaderSize;
+        return 0;
+    case ZSTDds_decodeSkippableHeader:
+        memcpy(c->headerBuffer + (8 - srcSize), src, srcSize);
+        c->expected = rdLE32(c->headerBuffer + 4);
+        c->stage = ZSTDds_skipFrame;
+        return 0;
+    case ZSTDds_skipFrame:
+        c->expected = 0;
+        c->stage = ZSTDds_getFrameHeaderSize;
+        return 0;
+    default:
+        return ERR(GENERIC);
+    }
+}

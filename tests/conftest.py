@@ -106,3 +106,24 @@ def verdict_of(out, err):
     if err:
         return {"error": err}
     return {"size": len(out), "sha256": hashlib.sha256(out).hexdigest()}
+
+
+# what libzstd 1.4.8 does through its bufferless interface on every frame above (tools/gen_continue_fixtures.py)
+def load_continue_entries():
+    with open(os.path.join(GOLD, "continue_traces.json")) as f:
+        return json.load(f)["entries"]
+
+
+CONTINUE_ENTRIES = load_continue_entries()
+CONTINUE_IDS = ["%s%s-%s" % (x["set"] + "/" if x["set"] else "", x["name"], x["variant"]) for x in CONTINUE_ENTRIES]
+CONTINUE_KEYS = ("steps", "trace_sha256", "err", "consumed", "out_size", "out_sha256", "frames")
+_BY_SET = {"": {e["name"]: e for e in FRAMES}, "params": {e["name"]: e for e in PARAM_FRAMES},
+           "divergent": {e["name"]: e for e in DIVERGENT_FRAMES}}
+
+
+def continue_input(x):
+    """(frame bytes, manifest entry, dictionary or None) of an entry of continue_traces.json."""
+    e = _BY_SET[x["set"]][x["name"]]
+    with open(os.path.join(GOLD, x["set"], e["file"]), "rb") as f:
+        data = f.read()
+    return data, e, read_dict(e.get("dict"))

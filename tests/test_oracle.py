@@ -104,3 +104,18 @@ def test_divergent_fixtures_every_verdict(e):
     finally:
         oracle.set_body(oracle.BODY_AS_ZSTD_148)
         oracle.set_huf(0)
+
+
+from conftest import CONTINUE_ENTRIES, CONTINUE_IDS, CONTINUE_KEYS, continue_input  # noqa: E402
+import continue_driver as cd  # noqa: E402
+
+
+@pytest.mark.parametrize("x", CONTINUE_ENTRIES, ids=CONTINUE_IDS)
+def test_oracle_bufferless_interface_matches_libzstd(x):
+    """ZSTD_decompressBegin[_usingDict] / ZSTD_nextSrcSizeToDecompress / ZSTD_nextInputType / ZSTD_decompressContinue
+    (zstd_decompressf.pas:995-1246, :1386-1421): every call's input type, size and result, the first error and the output
+    are those libzstd 1.4.8 recorded in tests/golden/continue_traces.json."""
+    data, e, d = continue_input(x)
+    be = cd.OracleBackend(bool(e.get("format", 0)), bool(e.get("ignore_checksum", 0)))
+    r = cd.drive(be, data, e["capacity"], d, raw_chunk=x["raw_chunk"])
+    assert {k: r[k] for k in CONTINUE_KEYS} == {k: x[k] for k in CONTINUE_KEYS}
