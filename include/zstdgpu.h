@@ -137,6 +137,29 @@ size_t zstdgpu_initDStream_usingDDict(zstdgpu_dstream* zds, const zstdgpu_ddict*
 size_t zstdgpu_resetDStream(zstdgpu_dstream* zds);                                 /* ZSTD_resetDStream :1630 */
 size_t zstdgpu_decompressStream(zstdgpu_dstream* zds, zstdgpu_outBuffer* output, zstdgpu_inBuffer* input);   /* :1978 */
 
+/* ---- bufferless streaming, one block per call (decompress/zstd_decompressf.pas:995-1246, :1386-1452)
+ * ZSTD_decompressBegin :1386, ZSTD_decompressBegin_usingDict :1410, ZSTD_decompressBegin_usingDDict :1426,
+ * ZSTD_nextSrcSizeToDecompress :995, ZSTD_nextInputType :1019, ZSTD_decompressContinue :1050.
+ * The caller asks how many bytes come next, hands over exactly that many (a raw block may come in pieces), and gets the
+ * bytes of every block back from the call that brought the block: 0 for header, checksum and skippable-frame calls, the
+ * regenerated size for block calls, or an error.  The stage machine is the reference's.  A compressed block is decoded by
+ * the GPU stage chain with the state the blocks before it left (entropy tables, repeat offsets, window) held on the device.
+ * Host buffers in and out.  One frame at a time per context; after a frame's last call zstdgpu_nextSrcSizeToDecompress
+ * returns 0 and Begin starts the next frame.  Differences from the reference, both of them slack: where the caller puts
+ * the output pieces does not matter (the window is a device buffer of the context, not the caller's memory), and frames
+ * with a window above 2^30 bytes are refused (frameParameter_windowTooLarge).  The context's format and checksum
+ * parameters apply.  After an error the frame cannot be continued (Begin again). */
+typedef enum {
+    ZSTDGPU_nit_frameHeader = 0, ZSTDGPU_nit_blockHeader = 1, ZSTDGPU_nit_block = 2, ZSTDGPU_nit_lastBlock = 3,
+    ZSTDGPU_nit_checksum = 4, ZSTDGPU_nit_skippableFrame = 5
+} zstdgpu_nextInputType_e;                                                          /* ZSTD_nextInputType_e common/zstd.pas:584 */
+size_t   zstdgpu_decompressBegin(zstdgpu_ctx* ctx);
+size_t   zstdgpu_decompressBegin_usingDict(zstdgpu_ctx* ctx, const void* dict, size_t dictSize);
+size_t   zstdgpu_decompressBegin_usingDDict(zstdgpu_ctx* ctx, const zstdgpu_ddict* ddict);
+size_t   zstdgpu_nextSrcSizeToDecompress(zstdgpu_ctx* ctx);
+unsigned zstdgpu_nextInputType(zstdgpu_ctx* ctx);
+size_t   zstdgpu_decompressContinue(zstdgpu_ctx* ctx, void* dst, size_t dstCapacity, const void* src, size_t srcSize);
+
 /* ---- decoder parameters (ZSTD_dParameter common/zstd.pas:289-309, :580-582; decompress/zstd_decompressf.pas:1641-1826)
  * As in the reference, where a stream is the decoding context itself, parameters and the referenced dictionary
  * belong to the context: they apply to zstdgpu_decompressDCtx, to batches built from frame entries

@@ -100,6 +100,36 @@ class OracleBackend(Backend):
         return (0 if c else r), c
 
 
+class GpuBackend(Backend):
+    """The library under test, through its C ABI (zstd_amd.api is a ctypes layer)."""
+
+    def __init__(self, dctx, use_ddict=False):
+        from zstd_amd import api
+        self.api, self.dctx, self.use_ddict = api, dctx, use_ddict
+        self._dd = None
+
+    def _code(self, r):
+        return self.api.ZSTD_getErrorCode(r) if self.api.ZSTD_isError(r) else 0
+
+    def begin(self, dictionary):
+        if dictionary and self.use_ddict:
+            if self._dd is None:
+                self._dd = self.api.DDict(self.dctx, dictionary)
+            return self._code(self.dctx.decompress_begin(ddict=self._dd))
+        return self._code(self.dctx.decompress_begin(dictionary))
+
+    def next_size(self):
+        return self.dctx.next_src_size_to_decompress()
+
+    def next_type(self):
+        return self.dctx.next_input_type()
+
+    def cont(self, dst_addr, cap, src):
+        r = self.dctx.decompress_continue(dst_addr, cap, src)
+        c = self._code(r)
+        return (0 if c else r), c
+
+
 def drive(be: Backend, data: bytes, capacity: int, dictionary: bytes = None, raw_chunk: int = 0, keep_steps: bool = False):
     """Decode `data` (one or more frames) into one contiguous buffer of `capacity` bytes the way a caller of the
     bufferless interface does: ask for the next size, hand over exactly that many bytes (a raw block in pieces of

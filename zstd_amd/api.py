@@ -73,6 +73,8 @@ EXPORTS = (
     "zstdgpu_decode_frames_noalloc",
     "zstdgpu_xxh64Batch", "zstdgpu_predefinedTables", "zstdgpu_batch_blockInfo", "zstdgpu_batch_copyLiterals", "zstdgpu_batch_copySequences",
     "zstdgpu_test_setExecuteKernel", "zstdgpu_batch_kernelVariants",
+    "zstdgpu_decompressBegin", "zstdgpu_decompressBegin_usingDict", "zstdgpu_decompressBegin_usingDDict",
+    "zstdgpu_nextSrcSizeToDecompress", "zstdgpu_nextInputType", "zstdgpu_decompressContinue",
 )
 
 
@@ -165,6 +167,12 @@ def lib():
     proto("zstdgpu_batch_copySequences", sz, vp, u32, vp, sz)
     proto("zstdgpu_test_setExecuteKernel", sz, vp, ci)
     proto("zstdgpu_batch_kernelVariants", u32, vp)
+    proto("zstdgpu_decompressBegin", sz, vp)
+    proto("zstdgpu_decompressBegin_usingDict", sz, vp, vp, sz)
+    proto("zstdgpu_decompressBegin_usingDDict", sz, vp, vp)
+    proto("zstdgpu_nextSrcSizeToDecompress", sz, vp)
+    proto("zstdgpu_nextInputType", ctypes.c_uint, vp)
+    proto("zstdgpu_decompressContinue", sz, vp, vp, sz, vp, sz)
     _lib = L
     return L
 
@@ -174,6 +182,14 @@ def ZSTD_dParam_getBounds(param: int):
     b = lib().zstdgpu_dParam_getBounds(param)
     _check(b.error)
     return b.lowerBound, b.upperBound
+
+
+def ZSTD_isError(r: int) -> bool:
+    return bool(lib().zstdgpu_isError(r))
+
+
+def ZSTD_getErrorCode(r: int) -> int:
+    return lib().zstdgpu_getErrorCode(r)
 
 
 def _check(r: int) -> int:
@@ -259,6 +275,25 @@ class DCtx:
         """Tests and measurements: send every frame of later launches to one of the two execute kernels
         ("one" wave per frame, "eight" waves per frame), or leave the choice to the library ("auto")."""
         _check(lib().zstdgpu_test_setExecuteKernel(self.h, self.EXECUTE_KERNELS[kernel]))
+
+    # bufferless, one block per call (decompress/zstd_decompressf.pas:995-1246, :1386-1452); results are raw size_t values
+    # (a count or an error, test with ZSTD_isError) as in the reference, because a caller acts on either
+    def decompress_begin(self, dictionary: bytes = None, ddict=None) -> int:
+        L = lib()
+        if ddict is not None:
+            return L.zstdgpu_decompressBegin_usingDDict(self.h, ddict.h)
+        if dictionary:
+            return L.zstdgpu_decompressBegin_usingDict(self.h, dictionary, len(dictionary))
+        return L.zstdgpu_decompressBegin(self.h)
+
+    def next_src_size_to_decompress(self) -> int:
+        return lib().zstdgpu_nextSrcSizeToDecompress(self.h)
+
+    def next_input_type(self) -> int:
+        return lib().zstdgpu_nextInputType(self.h)
+
+    def decompress_continue(self, dst_addr: int, dst_capacity: int, src: bytes) -> int:
+        return lib().zstdgpu_decompressContinue(self.h, dst_addr, dst_capacity, src, len(src))
 
     def close(self):
         if self.h:

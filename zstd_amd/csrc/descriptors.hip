@@ -230,8 +230,10 @@ __global__ __launch_bounds__(64) void k_fill_blocks(const uint8_t* src, uint64_t
     if (fr.hostError) return;
     uint32_t const first = fr.firstBlock;
     // entropy state carried from block to block inside the frame: which block defines each table
-    int32_t hufDef = dictEntropy ? SRC_DICT : SRC_NONE;
-    int32_t llDef = hufDef, ofDef = hufDef, mlDef = hufDef;
+    // (dictEntropy: bit 0 the dictionary brings a Huffman table, bit 1 it brings the three sequence tables; a digested
+    // dictionary brings both, the state carried from block to block by zstdgpu_decompressContinue what the blocks so far set)
+    int32_t hufDef = (dictEntropy & 1u) ? SRC_DICT : SRC_NONE;
+    int32_t llDef = (dictEntropy & 2u) ? SRC_DICT : SRC_NONE, ofDef = llDef, mlDef = llDef;
     bool dead = false;      // an error found here ends the frame: later blocks are never reached
     DevFrame f;
     uint32_t n;

@@ -615,7 +615,7 @@ __global__ __launch_bounds__(kDictTable ? 64 * kHufDictWaves : 64) __attribute__
     // Which decoder the reference runs on this block's streams: the double-symbol one for a dictionary's table
     // (zstd_decompressf.pas:1288) and where HUF_selectDecoder picked it for the block that defined the table (four
     // streams only: a single-stream block always builds the single-symbol table, huf_decompress.pas:1386).
-    bool x2 = fromDict;
+    bool x2 = fromDict && p.dict->hufX1 == 0;
     if (!kDictTable && blk.hufSrc >= 0) {
         uint32_t dSingle = blk.singleStream, dLit = blk.litSize, dC = blk.litCSize;
         if (blk.hufSrc != (int32_t)b) { const DevBlock* const sbp = p.blocks + blk.hufSrc; dSingle = sbp->singleStream; dLit = sbp->litSize; dC = sbp->litCSize; }
@@ -3735,6 +3735,7 @@ __global__ __launch_bounds__(64) void k_digest_dict(const uint8_t* dict, uint32_
     if (threadIdx.x != 0) return;
     out->status = E_dictionary_corrupted;
     out->hasEntropy = 1;
+    out->hufX1 = 0; out->entropyValid = 3;
     if (dictSize <= 8) return;
     uint32_t o = 8;
     {   // Huffman table for literals; the reference builds the double-symbol form here (:1288), which decodes the same bytes
@@ -3772,6 +3773,124 @@ __global__ __launch_bounds__(64) void k_digest_dict(const uint8_t* dict, uint32_
     }
     out->entropySize = o;
     out->status = 0;
+}
+
+// ---------------------------------------------------------------- block-at-a-time decoding (single lane)
+// ZSTD_decompressContinue (zstd_decompressf.pas:1137-1207) hands the decoder one block per call; what a block leaves
+// behind for the next one is the context's entropy state (zstd_ddict.pas:109-126): the Huffman table and the three
+// sequence tables last defined, and the repeat offsets.  The host decodes such a block as the only block of a frame
+// whose "dictionary" is that state (`carry`, in the dictionary's cell formats; its content is the output so far); this
+// kernel, run behind the block's stage chain, moves the tables the block defined and its final repeat offsets into the
+// state.  Frame 0 of the launch, its first block.
+__global__ __launch_bounds__(64) void k_carry_entropy(BatchParams p, DevDict* carry)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t scratch[2048];
+    __shared__ uint8_t weights[256];
+    __shared__ uint16_t pos[256];
+    __shared__ uint32_t rank[16];
+    __shared__ int16_t norm[64];
+    __shared__ uint16_t symNext[64];
+    if (threadIdx.x != 0) return;
+    if (batch_overflow(p) || p.status[0].errorCode) return;     // (the caller gives up the frame on an error: the state no longer matters)
+    DevFrame const f = p.frames[0];
+    if (f.hostError || f.nBlocks == 0) return;
+    uint32_t const b = f.firstBlock;
+    DevBlock const blk = p.blocks[b];
+    if (blk.blockType != BT_COMPRESSED) return;
+    const uint8_t* const payload = p.src + blk.srcOff;
+    if (blk.litType == SET_COMPRESSED) {
+        // HUF_readDTableX1 / X2 on the block's own description (zstd_decompress_block.pas:333-366); one cell format here
+        uint32_t nbSymbols = 0, tableLog = 0;
+        uint32_t const h = dev_huf_read_table_desc(payload + blk.litHdrSize, blk.litCSize, weights, pos, rank, scratch, nbSymbols, tableLog);
+        if (h != kFail) {
+            for (uint32_t n = 0; n < nbSymbols; n++) {
+                uint32_t const w = weights[n];
+                if (!w) continue;
+                uint32_t const len = (1u << w) >> 1;
+                uint16_t const cell = (uint16_t)(n | ((tableLog + 1 - w) << 8));
+                for (uint32_t u = 0; u < len; u++) carry->huf[pos[n] + u] = cell;
+            }
+            carry->hufLog = tableLog;
+            // which decoder built it decides how a later block that repeats the table judges its streams' last symbols
+            carry->hufX1 = (!blk.singleStream && blk.litSize != 0 && huf_select_x2(blk.litSize, blk.litCSize)) ? 0u : 1u;
+            carry->entropyValid |= 1u;
+        }
+    }
+    if (blk.nbSeq) {
+        uint32_t o = blk.seqHdrOff;
+        bool bad = false;
+        for (int k = 0; k < 3 && !bad; k++) {       // descriptions in the order LL, OF, ML (:744-781)
+            int const t = k == 0 ? T_LL : k == 1 ? T_OF : T_ML;
+            uint32_t const type = t == T_LL ? blk.llType : t == T_OF ? blk.ofType : blk.mlType;
+            if (type == SET_REPEAT) continue;
+            uint32_t* const cells = t == T_LL ? carry->ll : t == T_OF ? carry->of : carry->ml;
+            uint32_t lg = 0;
+            if (o > blk.cSize) { bad = true; break; }
+            uint32_t const h = dev_build_from_desc(t, type, payload + o, blk.cSize - o, cells, norm, symNext, lg);
+            if (h == kFail) { bad = true; break; }
+            if (t == T_LL) carry->llLog = lg; else if (t == T_OF) carry->ofLog = lg; else carry->mlLog = lg;
+            o += h;
+        }
+        if (!bad) carry->entropyValid |= 2u;
+        const DevBlockState* const st = p.state + b;
+        uint32_t const in[3] = {st->repIn[0], st->repIn[1], st->repIn[2]};
+        uint32_t const n0 = rep_resolve(st->repOut[0], in), n1 = rep_resolve(st->repOut[1], in), n2 = rep_resolve(st->repOut[2], in);
+        carry->rep[0] = n0; carry->rep[1] = n1; carry->rep[2] = n2;
+    }
+}
+
+// XXH64 in pieces (XXH64_reset / XXH64_update / XXH64_digest, xxhash.pas:533-545, :686-757, :759-828), for output that
+// arrives block by block: lanes 0..3 carry the four accumulators; after every piece the digest of everything so far is
+// left in the state, so the host reads it when the frame's checksum arrives.
+__global__ __launch_bounds__(64) void k_xxh64_stream(DevXxhState* s, const uint8_t* data, uint64_t len)
+{
+    uint32_t const w = threadIdx.x;
+    if (w >= 4) return;
+    uint64_t acc = s->v[w];
+    uint32_t const memsize = s->memsize;
+    uint64_t const total = s->total + len;
+    uint8_t mem[32];
+#pragma unroll
+    for (int i = 0; i < 32; i++) mem[i] = s->mem[i];
+    uint32_t newMem;
+    if (memsize + len < 32) {
+        for (uint32_t i = 0; i < (uint32_t)len; i++) mem[memsize + i] = data[i];
+        newMem = memsize + (uint32_t)len;
+    } else {
+        const uint8_t* q = data;
+        uint64_t left = len;
+        if (memsize) {
+            uint32_t const take = 32 - memsize;
+            for (uint32_t i = 0; i < take; i++) mem[memsize + i] = q[i];
+            uint64_t word = 0;
+            for (int j = 0; j < 8; j++) word |= (uint64_t)mem[8 * w + j] << (8 * j);
+            acc = xxh_round(acc, word);
+            q += take; left -= take;
+        }
+        uint64_t const stripes = left / 32;
+        for (uint64_t i = 0; i < stripes; i++) acc = xxh_round(acc, ld_u64(q + 32 * i + 8 * w));
+        q += 32 * stripes; left -= 32 * stripes;
+        for (uint32_t i = 0; i < (uint32_t)left; i++) mem[i] = q[i];
+        newMem = (uint32_t)left;
+    }
+    uint64_t const v1 = __shfl(acc, 0), v2 = __shfl(acc, 1), v3 = __shfl(acc, 2), v4 = __shfl(acc, 3);
+    s->v[w] = acc;
+    if (w == 0) {
+        s->total = total; s->memsize = newMem;
+        for (uint32_t i = 0; i < newMem; i++) s->mem[i] = mem[i];
+        uint64_t h;
+        if (total >= 32) {
+            h = rotl64(v1, 1) + rotl64(v2, 7) + rotl64(v3, 12) + rotl64(v4, 18);
+            h = xxh_merge(h, v1); h = xxh_merge(h, v2); h = xxh_merge(h, v3); h = xxh_merge(h, v4);
+        } else h = v3 + P5;
+        h += total;
+        uint32_t t = 0;
+        while (t + 8 <= newMem) { uint64_t word = 0; for (int j = 0; j < 8; j++) word |= (uint64_t)mem[t + j] << (8 * j); h ^= xxh_round(0, word); h = rotl64(h, 27) * P1 + P4; t += 8; }
+        if (t + 4 <= newMem) { uint32_t w4 = 0; for (int j = 0; j < 4; j++) w4 |= (uint32_t)mem[t + j] << (8 * j); h ^= (uint64_t)w4 * P1; h = rotl64(h, 23) * P2 + P3; t += 4; }
+        while (t < newMem) { h ^= (uint64_t)mem[t] * P5; h = rotl64(h, 11) * P1; t++; }
+        h ^= h >> 33; h *= P2; h ^= h >> 29; h *= P3; h ^= h >> 32;
+        s->digest = h;
+    }
 }
 
 }  // namespace
@@ -3846,6 +3965,14 @@ void launch_xxh64(const uint8_t* base, const uint64_t* off, const uint64_t* len,
 {
     if (!n) return;
     hipLaunchKernelGGL(k_xxh64, dim3((n + 7) / 8), dim3(64), 0, (hipStream_t)stream, base, off, len, n, out);
+}
+void launch_carry_entropy(const BatchParams& p, DevDict* carry, void* stream)
+{
+    hipLaunchKernelGGL(k_carry_entropy, dim3(1), dim3(64), 0, (hipStream_t)stream, p, carry);
+}
+void launch_xxh64_stream(DevXxhState* state, const uint8_t* data, uint64_t len, void* stream)
+{
+    hipLaunchKernelGGL(k_xxh64_stream, dim3(1), dim3(64), 0, (hipStream_t)stream, state, data, len);
 }
 
 }  // namespace zg

@@ -82,7 +82,7 @@ size_t fixed_scratch_bytes() { return kScratchBytes; }
 // Device walk + stage chain inside a scratch area of fixed_scratch_bytes() at `ptr` (256-byte aligned): the body of the
 // entry point below, also used by the one-shot drop-ins with a scratch area that belongs to their context.
 size_t decode_frames_fixed(zstdgpu_ctx* ctx, uint8_t* ptr, const void* devSrc, size_t srcBytes, const zstdgpu_frame_in* devFrames, uint32_t nFrames,
-                           void* devDst, zstdgpu_frame_status* devStatus, const zstdgpu_ddict* ddict, void* stream)
+                           void* devDst, zstdgpu_frame_status* devStatus, const zstdgpu_ddict* ddict, void* stream, DevDict* carry)
 {
     auto mkerr = [](uint32_t code) { return (size_t)0 - (size_t)code; };
     if (!ctx || hipSetDevice(ctx->device) != hipSuccess) return mkerr(E_generic);
@@ -116,7 +116,7 @@ size_t decode_frames_fixed(zstdgpu_ctx* ctx, uint8_t* ptr, const void* devSrc, s
     static_assert(oBlocks < oState && oState < oFlags && oFlags < oLitJobs && (oLitJobs - oBlocks) % 16 == 0, "one zero fill covers blocks, states and flags");
     launch_zero(ptr + oBlocks, oLitJobs - oBlocks, s);
     launch_zero(ptr + oDryList, 16, s);
-    launch_fill_blocks((const uint8_t*)devSrc, srcBytes, (const FrameIn*)devFrames, nFrames, batchDictID, opts, (ddict && ddict->hasEntropy) ? 1u : 0u,
+    launch_fill_blocks((const uint8_t*)devSrc, srcBytes, (const FrameIn*)devFrames, nFrames, batchDictID, opts, ddict ? ddict->entropyMask : 0u,
                        frames, blocks, flags, kMaxBlocks, litJobs, seqJobs, totals, s, caps);
 
     // ---- the stage chain, grids sized for the capacities; the kernels take the real counts from `totals`
@@ -140,6 +140,7 @@ size_t decode_frames_fixed(zstdgpu_ctx* ctx, uint8_t* ptr, const void* devSrc, s
     launch_layout(p, s);
     launch_execute(p, s);
     launch_checksum(p, s);
+    if (carry) launch_carry_entropy(p, carry, s);      // block-at-a-time decoding: what the block leaves to the next one
     return hipGetLastError() == hipSuccess ? 0 : mkerr(E_generic);
 }
 

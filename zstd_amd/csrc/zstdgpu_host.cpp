@@ -364,6 +364,7 @@ extern "C" const char* zstdgpu_getErrorName(size_t code)
 
 // ===================================================================== context
 static void stream_detach(zstdgpu_dstream* z);      // a stream whose context is gone: every later call fails
+static void bufferless_free(zstdgpu_bufferless* b);
 
 extern "C" zstdgpu_ctx* zstdgpu_create(int device)
 {
@@ -382,6 +383,7 @@ extern "C" void zstdgpu_destroy(zstdgpu_ctx* ctx)
     for (auto* z : ctx->streams) stream_detach(z);
     for (auto* d : ctx->ddicts) d->ctx = nullptr;
     for (auto* b : ctx->batches) b->ctx = nullptr;
+    bufferless_free(ctx->bufferless);
     hipFree(ctx->dSrc); hipFree(ctx->dDst); hipFree(ctx->oneShotScratch); hipFree(ctx->oneShotIO);
     for (auto& sp : ctx->spare) hipFree(sp.p);
     delete ctx;
@@ -555,7 +557,7 @@ extern "C" zstdgpu_ddict* zstdgpu_createDDict(zstdgpu_ctx* ctx, const void* dict
     if (dictSize && hipMemcpy(d->dBytes, dict, dictSize, hipMemcpyHostToDevice) != hipSuccess) { zstdgpu_freeDDict(d); return nullptr; }
     // ZSTD_decompress_insertDictionary (zstd_decompressf.pas:1358-1384): magic -> entropy tables + content, else raw content
     if (dictSize >= 8 && rd32((const uint8_t*)dict) == kMagicDict) {
-        d->hasEntropy = 1;
+        d->hasEntropy = 1; d->entropyMask = 3;
         d->dictID = rd32((const uint8_t*)dict + 4);
         launch_digest_dict(d->dBytes, d->size, d->dDict, nullptr);
         uint32_t head[3] = {0, 0, 0};   // status, hasEntropy, entropySize
@@ -634,6 +636,7 @@ extern "C" zstdgpu_batch* zstdgpu_batch_create(zstdgpu_ctx* ctx, const void* hos
     B->ddict = ddict;
     const uint8_t* const src = (const uint8_t*)hostSrc;
     bool const dictEntropy = ddict && ddict->hasEntropy;
+    uint32_t const entropyMask = ddict ? ddict->entropyMask : 0u;      // bit 0 Huffman table, bit 1 sequence tables
     uint32_t const batchDictID = ddict ? ddict->dictID : 0;
     uint64_t litOff = 0, seqOff = 0, tmpOff = 0;
     uint32_t ownTables = 0;      // sequence jobs with a table that is not the dictionary's
@@ -656,8 +659,8 @@ extern "C" zstdgpu_batch* zstdgpu_batch_create(zstdgpu_ctx* ctx, const void* hos
         if (f.hostError) { f.nBlocks = 0; f.longWindow = 0; continue; }
         B->srcBytes += fd.srcSize;
         // entropy state carried from block to block inside the frame (zstd_ddict.pas:109-126): which block defines each table
-        int32_t hufDef = dictEntropy ? SRC_DICT : SRC_NONE;
-        int32_t llDef = hufDef, ofDef = hufDef, mlDef = hufDef;
+        int32_t hufDef = (entropyMask & 1u) ? SRC_DICT : SRC_NONE;
+        int32_t llDef = (entropyMask & 2u) ? SRC_DICT : SRC_NONE, ofDef = llDef, mlDef = llDef;
         bool dead = false;   // a host-detected error ends the frame: later blocks are never reached
         for (uint32_t b = fd.firstBlock; b < fd.firstBlock + fd.nBlocks; b++) {
             const zstdgpu_block_desc& bd = blocks[b];
@@ -759,7 +762,7 @@ extern "C" zstdgpu_batch* zstdgpu_batch_create_on_device(zstdgpu_ctx* ctx, const
          dalloc(B->dLitJobs, nBlocks, B->scratchBytes) && dalloc(B->dSeqJobs, nBlocks, B->scratchBytes);
     ok = ok && hipMemset(B->dBlocks, 0, (size_t)(nBlocks ? nBlocks : 1) * sizeof(DevBlock)) == hipSuccess && hipMemset(dFlags, 0, nBlocks ? nBlocks : 1) == hipSuccess;
     if (ok) {
-        launch_fill_blocks((const uint8_t*)devSrc, srcBytes, dIn, nFrames, batchDictID, (ddict ? (uint32_t)kOptDict : 0u) | ctx->opts(), (ddict && ddict->hasEntropy) ? 1u : 0u,
+        launch_fill_blocks((const uint8_t*)devSrc, srcBytes, dIn, nFrames, batchDictID, (ddict ? (uint32_t)kOptDict : 0u) | ctx->opts(), ddict ? ddict->entropyMask : 0u,
                            B->dFrames, B->dBlocks, dFlags, nBlocks, B->dLitJobs, B->dSeqJobs, dTotals, nullptr);
         ok = hipMemcpy(totals, dTotals, sizeof(totals), hipMemcpyDeviceToHost) == hipSuccess;
     }
@@ -1427,6 +1430,339 @@ try {
     }
 }
 catch (...) { return mkerr(E_memory_allocation); }      // the C ABI never throws (std::bad_alloc from the host containers)
+
+// ===================================================================== bufferless, block at a time
+// ZSTD_decompressBegin[_usingDict|_usingDDict] / ZSTD_nextSrcSizeToDecompress / ZSTD_nextInputType /
+// ZSTD_decompressContinue (zstd_decompressf.pas:995-1246, :1386-1452): the caller hands over exactly the bytes asked
+// for -- a frame header, a block header, a block, a checksum -- and gets every block's bytes back from the call that
+// brought the block.  The stage machine is the reference's, on the host.  A compressed block is decoded on the GPU as
+// the only block of a frame of its own whose "dictionary" is what the blocks before it left behind: the entropy state
+// (Huffman table, three sequence tables, repeat offsets, in the cell formats of a digested dictionary; k_carry_entropy
+// moves a block's own tables into it) and the frame's output so far as the dictionary's content (the window).  The
+// kernels are the batch's; nothing in them knows about this interface.
+// Where the reference keeps the window in the caller's buffers (ZSTD_checkContinuity, zstd_decompress_block.pas:1545-1554),
+// the window here is a device buffer of the context: the last windowSize + dictionary bytes of output stay in it, and
+// where the caller puts the pieces does not matter.
+struct zstdgpu_bufferless {
+    enum Stage { getFrameHeaderSize = 0, decodeFrameHeader, decodeBlockHeader, decompressBlock, decompressLastBlock, checkChecksum,
+                 decodeSkippableHeader, skipFrame };       // ZSTD_dStage (zstd_ddict.pas:96-100)
+    bool begun = false;
+    Stage stage = getFrameHeaderSize;
+    size_t expected = 0, headerSize = 0, rleSize = 0;
+    uint8_t headerBuffer[18] = {0};                        // ZSTD_FRAMEHEADERSIZE_MAX
+    FrameHeader fh;
+    uint32_t blockSizeMax = 0, bType = 3, dictID = 0;
+    bool validateChecksum = false;
+    uint64_t decodedSize = 0;
+    // the state a block hands to the next one, shaped as a dictionary for the kernels: dDict = entropy tables and repeat
+    // offsets, dBytes[0, size) = the window (dictionary content, then the frame's output so far)
+    zstdgpu_ddict state;
+    size_t histCap = 0;
+    size_t keep = 0;              // bytes before the next block that a match may reach: window size + dictionary content
+    size_t dictContent = 0;
+    DevXxhState* dXxh = nullptr;
+    std::vector<uint8_t> mini;    // the block wrapped as a frame
+};
+
+static void bufferless_free(zstdgpu_bufferless* b)
+{
+    if (!b) return;
+    hipFree(b->state.dBytes); hipFree(b->state.dDict); hipFree(b->dXxh);
+    delete b;
+}
+
+namespace {
+
+constexpr size_t kBlHeadBytes = offsetof(DevDict, huf);       // the scalar fields of the carried state
+
+// room for n more bytes of window: grow the buffer until it holds twice what must be kept (plus two blocks), then move
+// the part to keep to the front when it is full (source and destination of that copy cannot overlap then)
+bool window_room(zstdgpu_bufferless* b, size_t n)
+{
+    size_t const len = b->state.size;
+    if (len + n <= b->histCap) return true;
+    size_t const K = b->keep;
+    if (len > K && len - K >= K) {
+        if (K && hipMemcpy(b->state.dBytes, b->state.dBytes + (len - K), K, hipMemcpyDeviceToDevice) != hipSuccess) return false;
+        b->state.size = (uint32_t)K;
+        if (K + n <= b->histCap) return true;
+    }
+    size_t const len2 = b->state.size;
+    size_t const full = 2 * K + 2 * (size_t)kBlockSizeMax + 64;
+    size_t want = std::max(len2 + n + 64, std::min(full, 2 * b->histCap + 65536));
+    if (want > 0xFFFFFF00ull) return false;
+    uint8_t* p = nullptr;
+    if (hipMalloc((void**)&p, want) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (len2 && hipMemcpy(p, b->state.dBytes, len2, hipMemcpyDeviceToDevice) != hipSuccess) { hipFree(p); return false; }
+    hipFree(b->state.dBytes);
+    b->state.dBytes = p; b->histCap = want;
+    return true;
+}
+
+// what ZSTD_decompressBegin leaves (zstd_decompressf.pas:1386-1408) plus, when given, the dictionary (:1358-1384, :1426-1452)
+size_t bufferless_begin(zstdgpu_ctx* ctx, const zstdgpu_ddict* ddict)
+try {
+    if (!ctx || !set_device(ctx)) return mkerr(E_generic);
+    if (ddict && ddict->status) return mkerr(E_dictionary_corrupted);
+    zstdgpu_bufferless* b = ctx->bufferless;
+    if (!b) {
+        b = new (std::nothrow) zstdgpu_bufferless;
+        if (!b) return mkerr(E_memory_allocation);
+        b->state.ctx = nullptr; b->state.device = ctx->device;
+        if (hipMalloc((void**)&b->state.dDict, sizeof(DevDict)) != hipSuccess || hipMalloc((void**)&b->dXxh, sizeof(DevXxhState)) != hipSuccess) {
+            (void)hipGetLastError(); bufferless_free(b); return mkerr(E_memory_allocation);
+        }
+        ctx->bufferless = b;
+    }
+    b->begun = false;
+    b->expected = ctx->format ? 1 : 5;          // ZSTD_startingInputLength (:96-107)
+    b->stage = zstdgpu_bufferless::getFrameHeaderSize;
+    b->decodedSize = 0; b->bType = 3; b->dictID = 0; b->validateChecksum = false;
+    b->state.size = 0; b->state.entropySize = 0; b->state.dictID = 0; b->state.status = 0; b->state.hasEntropy = 1; b->state.entropyMask = 0;
+    b->dictContent = 0; b->keep = 0;
+    // the scalar fields of the carried state: repeat offsets {1, 4, 8} (zstd_internal.pas:13), no table set yet
+    DevDict* const head = new (std::nothrow) DevDict;
+    if (!head) return mkerr(E_memory_allocation);
+    memset(head, 0, kBlHeadBytes);
+    head->hasEntropy = 1; head->rep[0] = 1; head->rep[1] = 4; head->rep[2] = 8;
+    bool ok = true;
+    if (ddict && ddict->size) {
+        if (ddict->hasEntropy) {
+            // the dictionary's digested tables and repeat offsets become the state; its content becomes the window
+            ok = hipMemcpy(b->state.dDict, ddict->dDict, sizeof(DevDict), hipMemcpyDeviceToDevice) == hipSuccess;
+            b->state.entropyMask = 3;
+            b->dictID = ddict->dictID;
+        } else ok = hipMemcpy(b->state.dDict, head, kBlHeadBytes, hipMemcpyHostToDevice) == hipSuccess;
+        size_t const content = ddict->size - ddict->entropySize;
+        b->dictContent = content; b->keep = content;
+        ok = ok && window_room(b, content);
+        if (ok && content) ok = hipMemcpy(b->state.dBytes, ddict->dBytes + ddict->entropySize, content, hipMemcpyDeviceToDevice) == hipSuccess;
+        if (ok) b->state.size = (uint32_t)content;
+    } else ok = hipMemcpy(b->state.dDict, head, kBlHeadBytes, hipMemcpyHostToDevice) == hipSuccess;
+    delete head;
+    if (!ok) return mkerr(E_memory_allocation);
+    b->begun = true;
+    return 0;
+}
+catch (...) { return mkerr(E_memory_allocation); }
+
+// ZSTD_nextSrcSizeToDecompressWithInputSize (:1010-1017): a raw block may arrive in pieces
+size_t next_size_with_input(const zstdgpu_bufferless* b, size_t inputSize)
+{
+    if (!(b->stage == zstdgpu_bufferless::decompressBlock || b->stage == zstdgpu_bufferless::decompressLastBlock)) return b->expected;
+    if (b->bType != BT_RAW) return b->expected;
+    return std::min(std::max<size_t>(inputSize, 1), b->expected);
+}
+
+// window descriptor byte of the smallest window of at least w bytes (the block's own frame states the real frame's
+// window, which decides whether zstd 1.4.8 may take its prefetching sequence loop: above 2^24)
+uint8_t window_descriptor(uint64_t w)
+{
+    for (uint32_t e = 0; e <= 21; e++)
+        for (uint32_t m = 0; m < 8; m++) {
+            uint64_t const base = 1ull << (10 + e);
+            if (base + (base >> 3) * m >= w) return (uint8_t)((e << 3) | m);
+        }
+    return (uint8_t)((21u << 3) | 7u);
+}
+
+// One compressed block on the GPU (ZSTD_decompressBlock_internal, zstd_decompress_block.pas:1491-1542, with the context's
+// entropy state and window): returns the regenerated size or an error; the bytes are in ctx->dDst.
+size_t bufferless_block(zstdgpu_ctx* ctx, zstdgpu_bufferless* b, size_t dstCapacity, const uint8_t* src, size_t srcSize)
+{
+    if (srcSize >= kBlockSizeMax) return mkerr(E_srcSize_wrong);        // :1513
+    bool const magicless = ctx->format != 0;
+    b->mini.clear();
+    if (!magicless) { b->mini.push_back(0x28); b->mini.push_back(0xB5); b->mini.push_back(0x2F); b->mini.push_back(0xFD); }
+    b->mini.push_back(0x00);                                           // descriptor: window byte follows, no content size, no checksum, no dictionary ID
+    b->mini.push_back(window_descriptor(b->fh.windowSize));
+    uint32_t const bh = 1u | ((uint32_t)BT_COMPRESSED << 1) | ((uint32_t)srcSize << 3);
+    b->mini.push_back((uint8_t)bh); b->mini.push_back((uint8_t)(bh >> 8)); b->mini.push_back((uint8_t)(bh >> 16));
+    b->mini.insert(b->mini.end(), src, src + srcSize);
+    size_t const cap = std::min<size_t>(dstCapacity, 0x7FFFFFFEu);
+    if (!ctx->oneShotTried) {
+        ctx->oneShotTried = true;
+        if (hipMalloc((void**)&ctx->oneShotScratch, fixed_scratch_bytes()) != hipSuccess) ctx->oneShotScratch = nullptr;
+        if (hipMalloc((void**)&ctx->oneShotIO, ZSTDGPU_NOALLOC_MAX_FRAMES * (sizeof(zstdgpu_frame_in) + sizeof(zstdgpu_frame_status))) != hipSuccess) ctx->oneShotIO = nullptr;
+        (void)hipGetLastError();
+    }
+    if (!ctx->oneShotScratch || !ctx->oneShotIO) return mkerr(E_memory_allocation);
+    if (!ensure(ctx->dSrc, ctx->dSrcCap, b->mini.size() + 16) || !ensure(ctx->dDst, ctx->dDstCap, cap + 16)) return mkerr(E_memory_allocation);
+    if (hipMemcpy(ctx->dSrc, b->mini.data(), b->mini.size(), hipMemcpyHostToDevice) != hipSuccess) return mkerr(E_generic);
+    zstdgpu_frame_in const in{0, b->mini.size(), 0, cap};
+    zstdgpu_frame_in* const dIn = (zstdgpu_frame_in*)ctx->oneShotIO;
+    zstdgpu_frame_status* const dSt = (zstdgpu_frame_status*)(ctx->oneShotIO + ZSTDGPU_NOALLOC_MAX_FRAMES * sizeof(zstdgpu_frame_in));
+    if (hipMemcpy(dIn, &in, sizeof(in), hipMemcpyHostToDevice) != hipSuccess) return mkerr(E_generic);
+    size_t const rc = decode_frames_fixed(ctx, ctx->oneShotScratch, ctx->dSrc, b->mini.size(), dIn, 1, ctx->dDst, dSt, &b->state, nullptr, b->state.dDict);
+    if (rc) return rc;
+    zstdgpu_frame_status st{};
+    if (hipMemcpy(&st, dSt, sizeof(st), hipMemcpyDeviceToHost) != hipSuccess) return mkerr(E_generic);
+    if (st.errorCode) return mkerr(st.errorCode);
+    // which tables the state holds now (the walk of the next block wants to know)
+    uint32_t valid = 0;
+    if (hipMemcpy(&valid, (const uint8_t*)b->state.dDict + offsetof(DevDict, entropyValid), 4, hipMemcpyDeviceToHost) != hipSuccess) return mkerr(E_generic);
+    b->state.entropyMask = valid & 3u;
+    return (size_t)st.regenSize;
+}
+
+}  // namespace
+
+extern "C" size_t zstdgpu_decompressBegin(zstdgpu_ctx* ctx) { return bufferless_begin(ctx, nullptr); }
+extern "C" size_t zstdgpu_decompressBegin_usingDDict(zstdgpu_ctx* ctx, const zstdgpu_ddict* ddict) { return bufferless_begin(ctx, ddict); }
+extern "C" size_t zstdgpu_decompressBegin_usingDict(zstdgpu_ctx* ctx, const void* dict, size_t dictSize)
+{
+    if (!dict || !dictSize) return bufferless_begin(ctx, nullptr);
+    zstdgpu_ddict* d = zstdgpu_createDDict(ctx, dict, dictSize);
+    if (!d) return mkerr(E_memory_allocation);
+    size_t const r = bufferless_begin(ctx, d);      // (the state holds copies: the dictionary object is not needed afterwards)
+    zstdgpu_freeDDict(d);
+    return r;
+}
+extern "C" size_t zstdgpu_nextSrcSizeToDecompress(zstdgpu_ctx* ctx)
+{
+    return (ctx && ctx->bufferless && ctx->bufferless->begun) ? ctx->bufferless->expected : 0;
+}
+extern "C" unsigned zstdgpu_nextInputType(zstdgpu_ctx* ctx)
+{
+    if (!ctx || !ctx->bufferless) return ZSTDGPU_nit_frameHeader;
+    switch (ctx->bufferless->stage) {
+        default:
+        case zstdgpu_bufferless::getFrameHeaderSize: case zstdgpu_bufferless::decodeFrameHeader: return ZSTDGPU_nit_frameHeader;
+        case zstdgpu_bufferless::decodeBlockHeader: return ZSTDGPU_nit_blockHeader;
+        case zstdgpu_bufferless::decompressBlock: return ZSTDGPU_nit_block;
+        case zstdgpu_bufferless::decompressLastBlock: return ZSTDGPU_nit_lastBlock;
+        case zstdgpu_bufferless::checkChecksum: return ZSTDGPU_nit_checksum;
+        case zstdgpu_bufferless::decodeSkippableHeader: case zstdgpu_bufferless::skipFrame: return ZSTDGPU_nit_skippableFrame;
+    }
+}
+
+extern "C" size_t zstdgpu_decompressContinue(zstdgpu_ctx* ctx, void* dstv, size_t dstCapacity, const void* srcv, size_t srcSize)
+try {
+    typedef zstdgpu_bufferless BL;
+    if (!ctx || !set_device(ctx)) return mkerr(E_generic);
+    BL* const b = ctx->bufferless;
+    if (!b || !b->begun) return mkerr(E_stage_wrong);
+    uint8_t* const dst = (uint8_t*)dstv;
+    const uint8_t* const src = (const uint8_t*)srcv;
+    bool const magicless = ctx->format != 0;
+    if (srcSize != next_size_with_input(b, srcSize)) return mkerr(E_srcSize_wrong);
+    if (srcSize && !src) return mkerr(E_generic);
+    switch (b->stage) {
+    case BL::getFrameHeaderSize:
+        if (!magicless) {
+            if (srcSize < 4) return mkerr(E_srcSize_wrong);      // (the reference reads the magic number whatever it was given)
+            if ((rd32(src) & kMagicSkipMask) == kMagicSkipStart) {
+                memcpy(b->headerBuffer, src, srcSize);
+                b->expected = 8 - srcSize;                       // ZSTD_SKIPPABLEHEADERSIZE
+                b->stage = BL::decodeSkippableHeader;
+                return 0;
+            }
+        }
+        b->headerSize = frame_header_size(src, srcSize, magicless);
+        if (iserr(b->headerSize)) return b->headerSize;
+        memcpy(b->headerBuffer, src, srcSize);
+        b->expected = b->headerSize - srcSize;
+        b->stage = BL::decodeFrameHeader;
+        return 0;
+    case BL::decodeFrameHeader: {
+        memcpy(b->headerBuffer + (b->headerSize - srcSize), src, srcSize);
+        // ZSTD_decodeFrameHeader (:541-555; the dictionary ID check is zstd 1.4.8's, which the port dropped)
+        b->fh = FrameHeader{};
+        size_t const r = get_frame_header(b->fh, b->headerBuffer, b->headerSize, magicless);
+        if (iserr(r)) return r;
+        if (r > 0) return mkerr(E_srcSize_wrong);
+        if (b->fh.dictID && b->dictID != b->fh.dictID) return mkerr(E_dictionary_wrong);
+        // (sizes here are 32-bit as the port's are: a window that the device buffer's 32-bit length cannot hold twice over is refused)
+        if (b->fh.windowSize > (1ull << 30)) return mkerr(E_frameParameter_windowTooLarge);
+        b->validateChecksum = b->fh.checksumFlag && !ctx->ignoreChecksum;
+        if (b->validateChecksum) {
+            DevXxhState x{};                                     // XXH64_reset(seed 0) (xxhash.pas:533-545)
+            x.v[0] = 0x9E3779B185EBCA87ull + 0xC2B2AE3D27D4EB4Full; x.v[1] = 0xC2B2AE3D27D4EB4Full; x.v[2] = 0; x.v[3] = 0ull - 0x9E3779B185EBCA87ull;
+            x.digest = 0xEF46DB3751D8E999ull;                    // XXH64 of nothing
+            if (hipMemcpy(b->dXxh, &x, sizeof(x), hipMemcpyHostToDevice) != hipSuccess) return mkerr(E_generic);
+        }
+        b->blockSizeMax = (uint32_t)std::min<uint64_t>(b->fh.windowSize, kBlockSizeMax);
+        b->keep = (size_t)b->fh.windowSize + b->dictContent;
+        b->expected = 3;
+        b->stage = BL::decodeBlockHeader;
+        return 0;
+    }
+    case BL::decodeBlockHeader: {
+        // ZSTD_getcBlockSize (zstd_decompress_block.pas:190-207)
+        uint32_t const hdr = rd24(src);
+        uint32_t const last = hdr & 1, type = (hdr >> 1) & 3, size = hdr >> 3;
+        if (type == 3) return mkerr(E_corruption);
+        size_t const cBlockSize = type == BT_RLE ? 1 : size;
+        if (cBlockSize > b->blockSizeMax) return mkerr(E_corruption);
+        b->expected = cBlockSize; b->bType = type; b->rleSize = size;
+        if (cBlockSize) { b->stage = last ? BL::decompressLastBlock : BL::decompressBlock; return 0; }
+        if (last) {      // empty block
+            if (b->fh.checksumFlag) { b->expected = 4; b->stage = BL::checkChecksum; }
+            else { b->expected = 0; b->stage = BL::getFrameHeaderSize; }
+        } else { b->expected = 3; b->stage = BL::decodeBlockHeader; }
+        return 0;
+    }
+    case BL::decompressLastBlock:
+    case BL::decompressBlock: {
+        size_t rSize;
+        if (b->bType == BT_COMPRESSED) {
+            rSize = bufferless_block(ctx, b, dstCapacity, src, srcSize);
+            if (iserr(rSize)) return rSize;
+            b->expected = 0;
+            if (rSize > b->blockSizeMax) return mkerr(E_corruption);
+            if (!window_room(b, rSize)) return mkerr(E_memory_allocation);
+            if (rSize && hipMemcpy(b->state.dBytes + b->state.size, ctx->dDst, rSize, hipMemcpyDeviceToDevice) != hipSuccess) return mkerr(E_generic);
+            if (rSize && hipMemcpy(dst, ctx->dDst, rSize, hipMemcpyDeviceToHost) != hipSuccess) return mkerr(E_generic);
+        } else if (b->bType == BT_RAW) {
+            if (srcSize > dstCapacity) return mkerr(E_dstSize_tooSmall);       // ZSTD_copyRawBlock (zstd_decompressf.pas:699-713)
+            rSize = srcSize;
+            if (!window_room(b, rSize)) return mkerr(E_memory_allocation);
+            if (rSize && hipMemcpy(b->state.dBytes + b->state.size, src, rSize, hipMemcpyHostToDevice) != hipSuccess) return mkerr(E_generic);
+            if (rSize) memcpy(dst, src, rSize);
+            b->expected -= rSize;
+        } else {
+            if (b->rleSize > dstCapacity) return mkerr(E_dstSize_tooSmall);    // ZSTD_setRleBlock (:715-731)
+            rSize = b->rleSize;
+            b->expected = 0;
+            if (rSize > b->blockSizeMax) return mkerr(E_corruption);
+            if (!window_room(b, rSize)) return mkerr(E_memory_allocation);
+            if (rSize && hipMemset(b->state.dBytes + b->state.size, src[0], rSize) != hipSuccess) return mkerr(E_generic);
+            if (rSize) memset(dst, src[0], rSize);
+        }
+        if (rSize > b->blockSizeMax) return mkerr(E_corruption);
+        b->decodedSize += rSize;
+        if (b->validateChecksum && rSize) launch_xxh64_stream(b->dXxh, b->state.dBytes + b->state.size, rSize, nullptr);
+        b->state.size += (uint32_t)rSize;
+        if (b->expected > 0) return rSize;      // the rest of a raw block is still to come
+        if (b->stage == BL::decompressLastBlock) {
+            if (b->fh.contentSize != ZSTDGPU_CONTENTSIZE_UNKNOWN && b->decodedSize != b->fh.contentSize) return mkerr(E_corruption);
+            if (b->fh.checksumFlag) { b->expected = 4; b->stage = BL::checkChecksum; }
+            else { b->expected = 0; b->stage = BL::getFrameHeaderSize; }
+        } else { b->stage = BL::decodeBlockHeader; b->expected = 3; }
+        return rSize;
+    }
+    case BL::checkChecksum:
+        if (b->validateChecksum) {
+            uint64_t digest = 0;
+            if (hipMemcpy(&digest, &b->dXxh->digest, 8, hipMemcpyDeviceToHost) != hipSuccess) return mkerr(E_generic);
+            if (rd32(src) != (uint32_t)digest) return mkerr(E_checksum_wrong);
+        }
+        b->expected = 0;
+        b->stage = BL::getFrameHeaderSize;
+        return 0;
+    case BL::decodeSkippableHeader:
+        memcpy(b->headerBuffer + (8 - srcSize), src, srcSize);
+        b->expected = rd32(b->headerBuffer + 4);
+        b->stage = BL::skipFrame;
+        return 0;
+    case BL::skipFrame:
+        b->expected = 0;
+        b->stage = BL::getFrameHeaderSize;
+        return 0;
+    }
+    return mkerr(E_generic);
+}
+catch (...) { return mkerr(E_memory_allocation); }
 
 // ZSTD_decompress creates and frees its own context per call (zstd_decompressf.pas:977-988)
 extern "C" size_t zstdgpu_decompress(void* dst, size_t dstCapacity, const void* src, size_t srcSize)

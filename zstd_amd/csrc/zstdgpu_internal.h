@@ -92,13 +92,24 @@ struct DevDict {
     uint32_t hufLog;
     uint32_t llLog, ofLog, mlLog;
     uint32_t rep[3];
-    uint32_t pad[2];
+    uint32_t hufX1;         // 1: the Huffman table was built by the single-symbol decoder (a block's own table carried to the next block,
+                            // k_carry_entropy); 0: by the double-symbol one, as a dictionary's always is (zstd_decompressf.pas:1288)
+    uint32_t entropyValid;  // carried state only: bit 0 the Huffman table is set (litEntropy), bit 1 the sequence tables are (fseEntropy)
     uint16_t huf[kHufCells];   // {byte, nbBits<<8}
     uint32_t ll[512], of[256], ml[512];   // packed sequence cells
 };
 // (the kernels copy these tables 16 bytes at a time)
 static_assert(offsetof(DevDict, huf) % 16 == 0 && offsetof(DevDict, ll) % 16 == 0 && offsetof(DevDict, of) % 16 == 0 && offsetof(DevDict, ml) % 16 == 0,
               "dictionary tables are 16-byte aligned");
+
+// XXH64 of output that arrives in pieces (XXH64_state_t, xxhash.pas:57-66), with the digest of everything so far
+struct DevXxhState {
+    uint64_t v[4];
+    uint64_t total;
+    uint64_t digest;
+    uint32_t memsize, pad;
+    uint8_t mem[32];
+};
 
 struct BatchParams {
     const uint8_t* src;          // device source buffer
@@ -160,5 +171,7 @@ void launch_digest_dict(const uint8_t* devDict, uint32_t dictSize, DevDict* out,
 void launch_basic_tables(uint32_t* out /* [3][64][4] */, void* stream);
 void launch_zero(void* p /* 16-byte aligned */, size_t bytes /* multiple of 16 */, void* stream);
 void launch_xxh64(const uint8_t* base, const uint64_t* off, const uint64_t* len, uint32_t n, uint64_t* out, void* stream);
+void launch_carry_entropy(const BatchParams& p, DevDict* carry, void* stream);
+void launch_xxh64_stream(DevXxhState* state, const uint8_t* data, uint64_t len, void* stream);
 
 }  // namespace zg

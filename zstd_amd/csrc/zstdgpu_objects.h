@@ -9,6 +9,7 @@
 #include "zstdgpu_internal.h"
 
 struct zstdgpu_dstream;
+struct zstdgpu_bufferless;
 
 struct zstdgpu_ctx {
     int device = 0;
@@ -34,6 +35,7 @@ struct zstdgpu_ctx {
     uint8_t* oneShotIO = nullptr;                 // 256 frame entries, then 256 verdicts
     bool oneShotTried = false;
     bool oneShotFixed = true;                     // false for the context that zstdgpu_decompress makes for a single call
+    struct zstdgpu_bufferless* bufferless = nullptr;   // state of zstdgpu_decompressBegin / zstdgpu_decompressContinue (made at the first Begin)
     uint32_t execKernel = 0;                      // zstdgpu_test_setExecuteKernel: 0 chosen per launch, 1 one wave per frame, 2 eight
     uint32_t opts() const { return (format ? zg::kOptMagicless : 0u) | (ignoreChecksum ? zg::kOptIgnoreChecksum : 0u); }
     void reset_parameters() { format = 0; maxWindowSize = (1ull << 27) + 1; stableOut = 0; ignoreChecksum = 0; }
@@ -44,6 +46,7 @@ struct zstdgpu_ddict {
     uint8_t* dBytes = nullptr;     // whole dictionary on the device
     zg::DevDict* dDict = nullptr;
     uint32_t size = 0, dictID = 0, hasEntropy = 0, entropySize = 0, status = 0;
+    uint32_t entropyMask = 0;      // which tables the dictionary brings: bit 0 Huffman, bit 1 the three sequence tables (3 for a digested dictionary)
     int device = 0;
 };
 
@@ -53,6 +56,8 @@ namespace zg {
 uint8_t* noalloc_scratch(int device);
 // The body of zstdgpu_decode_frames_noalloc on a scratch area of fixed_scratch_bytes() given by the caller (noalloc.hip).
 size_t fixed_scratch_bytes();
+// carry: when set, the entropy state that the first block of frame 0 leaves behind is moved into it after the chain
+// (k_carry_entropy; zstdgpu_decompressContinue decodes one block per call this way).
 size_t decode_frames_fixed(zstdgpu_ctx* ctx, uint8_t* scratch, const void* devSrc, size_t srcBytes, const zstdgpu_frame_in* devFrames, uint32_t nFrames,
-                           void* devDst, zstdgpu_frame_status* devStatus, const zstdgpu_ddict* ddict, void* stream);
+                           void* devDst, zstdgpu_frame_status* devStatus, const zstdgpu_ddict* ddict, void* stream, DevDict* carry = nullptr);
 }  // namespace zg
