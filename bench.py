@@ -260,6 +260,49 @@ def one_shot_latency(dctx, calls: int = 200):
             "decompress_usingDDict_us_per_call": round(rebuilt * 1e6, 1), "prepared_batch_decode_and_status_us_per_call": round(reused * 1e6, 1)}
 
 
+def bufferless_latency(dctx):
+    """Per-call cost of the bufferless interface (zstdgpu_decompressContinue) on a committed frame of eight full blocks
+    (1 MiB of text, level 1), host buffers in and out: every compressed block is one pass of the stage chain."""
+    import ctypes
+    from zstd_amd import api
+    gold = os.path.join(ROOT, "tests", "golden")
+    e = {x["name"]: x for x in json.load(open(os.path.join(gold, "manifest.json")))["frames"]}["text1m_l1"]
+    fr = open(os.path.join(gold, e["file"]), "rb").read()
+    buf = ctypes.create_string_buffer(e["capacity"])
+    base = ctypes.addressof(buf)
+
+    def once():
+        assert not api.ZSTD_isError(dctx.decompress_begin())
+        pos = op = blocks = 0
+        t_blocks = 0.0
+        while True:
+            n = dctx.next_src_size_to_decompress()
+            if n == 0:
+                break
+            is_block = dctx.next_input_type() in (2, 3)
+            t0 = time.perf_counter()
+            r = dctx.decompress_continue(base + op, e["capacity"] - op, fr[pos:pos + n])
+            if is_block:
+                t_blocks += time.perf_counter() - t0
+                blocks += 1
+            assert not api.ZSTD_isError(r)
+            pos += n
+            op += r
+        return op, blocks, t_blocks
+
+    once()
+    t0 = time.perf_counter()
+    reps, tb, nb, size = 5, 0.0, 0, 0
+    for _ in range(reps):
+        size, b, t = once()
+        tb += t
+        nb += b
+    whole = (time.perf_counter() - t0) / reps
+    assert size == e["size"]
+    return {"frame": "tests/golden text1m_l1 (1 MiB, eight blocks)", "us_per_block_call": round(tb / nb * 1e6, 1),
+            "frame_ms": round(whole * 1e3, 2), "GBps": round(size / whole / 1e9, 3)}
+
+
 def spawn_ranks(args) -> int:
     """--gpus N > 1 without a launcher: start the N ranks as fresh processes (nothing here has touched a GPU)."""
     port = 29500 + (os.getpid() % 2000)
@@ -482,6 +525,7 @@ def main():
     }
     if world == 1 and not args.no_latency:
         out["one_shot_latency"] = one_shot_latency(dctx)
+        out["bufferless"] = bufferless_latency(dctx)
     if world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(frames, caps, w["dictionary"])
     print(json.dumps(out))

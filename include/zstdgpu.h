@@ -145,9 +145,9 @@ size_t zstdgpu_decompressStream(zstdgpu_dstream* zds, zstdgpu_outBuffer* output,
  * regenerated size for block calls, or an error.  The stage machine is the reference's.  A compressed block is decoded by
  * the GPU stage chain with the state the blocks before it left (entropy tables, repeat offsets, window) held on the device.
  * Host buffers in and out.  One frame at a time per context; after a frame's last call zstdgpu_nextSrcSizeToDecompress
- * returns 0 and Begin starts the next frame.  Differences from the reference, both of them slack: where the caller puts
- * the output pieces does not matter (the window is a device buffer of the context, not the caller's memory), and frames
- * with a window above 2^30 bytes are refused (frameParameter_windowTooLarge).  The context's format and checksum
+ * returns 0 and Begin starts the next frame.  Differences from the reference: where the caller puts the output pieces does
+ * not matter (the window is a device buffer of the context, not the caller's memory), and no more than the last 1.5 GB
+ * of output stay reachable for matches whatever window the frame header states.  The context's format and checksum
  * parameters apply.  After an error the frame cannot be continued (Begin again). */
 typedef enum {
     ZSTDGPU_nit_frameHeader = 0, ZSTDGPU_nit_blockHeader = 1, ZSTDGPU_nit_block = 2, ZSTDGPU_nit_lastBlock = 3,

@@ -3,7 +3,8 @@
  *
  * A plain-C, single-threaded CPU restatement of the one-shot zstd frame
  * decoder of the Free Pascal port terrylao/zstd (itself a transliteration of
- * upstream zstd 1.4.8).  It exists to check the HIP decoder; it is never part
+ * upstream zstd 1.4.8), and of its bufferless block-by-block interface
+ * (ZSTD_decompressContinue, at the end of the file).  It exists to check the HIP decoder; it is never part
  * of the shipped decode path.  Only tests/, __graft_entry__.smoke() and the
  * cpu_baseline leg of bench.py may load it.
  *

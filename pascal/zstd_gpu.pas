@@ -109,6 +109,15 @@ function zstdgpu_initDStream(zds: pointer): PtrUInt; cdecl; external ZSTDGPU_LIB
 function zstdgpu_initDStream_usingDDict(zds: pointer; ddict: pzstdgpu_ddict): PtrUInt; cdecl; external ZSTDGPU_LIB;
 function zstdgpu_resetDStream(zds: pointer): PtrUInt; cdecl; external ZSTDGPU_LIB;
 function zstdgpu_decompressStream(zds: pointer; output, input: pointer): PtrUInt; cdecl; external ZSTDGPU_LIB;
+{ bufferless streaming, one block per call: ZSTD_decompressBegin / _usingDict / _usingDDict, ZSTD_nextSrcSizeToDecompress,
+  ZSTD_nextInputType, ZSTD_decompressContinue (decompress/zstd_decompressf.pas:1386, :1410, :1426, :995, :1019, :1050);
+  zstdgpu_nextInputType returns ord(ZSTD_nextInputType_e) (common/zstd.pas:584) }
+function zstdgpu_decompressBegin(ctx: pzstdgpu_ctx): PtrUInt; cdecl; external ZSTDGPU_LIB;
+function zstdgpu_decompressBegin_usingDict(ctx: pzstdgpu_ctx; dict: pbyte; dictSize: PtrUInt): PtrUInt; cdecl; external ZSTDGPU_LIB;
+function zstdgpu_decompressBegin_usingDDict(ctx: pzstdgpu_ctx; ddict: pzstdgpu_ddict): PtrUInt; cdecl; external ZSTDGPU_LIB;
+function zstdgpu_nextSrcSizeToDecompress(ctx: pzstdgpu_ctx): PtrUInt; cdecl; external ZSTDGPU_LIB;
+function zstdgpu_nextInputType(ctx: pzstdgpu_ctx): LongWord; cdecl; external ZSTDGPU_LIB;
+function zstdgpu_decompressContinue(ctx: pzstdgpu_ctx; dst: pbyte; dstCapacity: PtrUInt; src: pbyte; srcSize: PtrUInt): PtrUInt; cdecl; external ZSTDGPU_LIB;
 { decoder parameters: ZSTD_DCtx_setParameter / getParameter / refDDict / reset, ZSTD_dParam_getBounds
   (decompress/zstd_decompressf.pas:1641-1826); param takes ord(ZSTD_dParameter) (100, 1000, 1001, 1002), reset takes
   ord(ZSTD_ResetDirective) }

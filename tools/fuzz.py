@@ -205,6 +205,22 @@ def run(args, dctx=None) -> int:
                     with open(fn, "wb") as f:
                         f.write(frames[i])
                     print(f"ONE-SHOT MISMATCH round {r} frame {i} err={gerr} wantErr={wantErr[i]} len={gl} wantLen={wantLen[i]} level={jobs[i][1]} -> {fn}", flush=True)
+        if getattr(args, "bufferless", False):
+            # the same frames (damaged or not) block by block through zstdgpu_decompressContinue: every call's size, kind and
+            # result and the bytes against the system libzstd driven by the same loop (tests/continue_driver.py)
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import continue_driver as cd
+            sysbe = cd.SystemBackend()
+            for i in range(len(jobs)):
+                got = cd.drive(cd.GpuBackend(dctx), frames[i], caps[i], dictionary, keep_steps=True)
+                ref = cd.drive(sysbe, frames[i], caps[i], dictionary, keep_steps=True)
+                if got["trace"] != ref["trace"] or got["out"] != ref["out"]:
+                    bad += 1
+                    fn = os.path.join(ROOT, "gpurun_out", f"fuzz_fail_bl_s{args.seed}_r{r}_{i}.zst")
+                    os.makedirs(os.path.dirname(fn), exist_ok=True)
+                    with open(fn, "wb") as f:
+                        f.write(frames[i])
+                    print(f"BUFFERLESS MISMATCH round {r} frame {i}: {cd.first_difference(got['trace'], ref['trace'])} cap={caps[i]} level={jobs[i][1]} -> {fn}", flush=True)
         if digests[0] != digests[1]:
             bad += 1
             print(f"DIGEST MISMATCH round {r}", flush=True)
@@ -223,6 +239,7 @@ def main():
     ap.add_argument("--corrupt", action="store_true", help="damage every frame (1-3 random bytes) and compare verdicts and bytes with the system libzstd (and the CPU oracle with it)")
     ap.add_argument("--dict", action="store_true", help="small frames compressed with a trained dictionary")
     ap.add_argument("--records", action="store_true", help="batches of 4 KB structured records compressed against a dictionary trained on such records (level 3)")
+    ap.add_argument("--bufferless", action="store_true", help="also decode every frame block by block through zstdgpu_decompressContinue and compare each call with the system libzstd's")
     bad = run(ap.parse_args())
     print("FUZZ", "FAILED" if bad else "OK")
     sys.exit(1 if bad else 0)

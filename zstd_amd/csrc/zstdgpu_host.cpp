@@ -1672,8 +1672,6 @@ try {
         if (iserr(r)) return r;
         if (r > 0) return mkerr(E_srcSize_wrong);
         if (b->fh.dictID && b->dictID != b->fh.dictID) return mkerr(E_dictionary_wrong);
-        // (sizes here are 32-bit as the port's are: a window that the device buffer's 32-bit length cannot hold twice over is refused)
-        if (b->fh.windowSize > (1ull << 30)) return mkerr(E_frameParameter_windowTooLarge);
         b->validateChecksum = b->fh.checksumFlag && !ctx->ignoreChecksum;
         if (b->validateChecksum) {
             DevXxhState x{};                                     // XXH64_reset(seed 0) (xxhash.pas:533-545)
@@ -1682,7 +1680,9 @@ try {
             if (hipMemcpy(b->dXxh, &x, sizeof(x), hipMemcpyHostToDevice) != hipSuccess) return mkerr(E_generic);
         }
         b->blockSizeMax = (uint32_t)std::min<uint64_t>(b->fh.windowSize, kBlockSizeMax);
-        b->keep = (size_t)b->fh.windowSize + b->dictContent;
+        // (the window buffer's length is 32-bit, as the port's sizes are, and must hold what is kept twice over: no more
+        // than 1.5 GB of output stays reachable, whatever window the header states; the buffer grows as output arrives)
+        b->keep = (size_t)std::min<uint64_t>(b->fh.windowSize + b->dictContent, 0x60000000ull);
         b->expected = 3;
         b->stage = BL::decodeBlockHeader;
         return 0;
