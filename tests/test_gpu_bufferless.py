@@ -72,6 +72,23 @@ def test_bufferless_long_frame_slides_its_window(dctx):
         assert got["trace"] == want["trace"]
 
 
+def test_bufferless_long_frame_with_dictionary(dctx):
+    """The same with a dictionary in front of the window: its content is reachable early in the frame and has left the
+    device window by the end; both forms of Begin."""
+    if not corpus.SystemZstd.available():
+        pytest.skip("needs the system libzstd to make the frame")
+    z = corpus.SystemZstd()
+    d = read_dict("dict16k")
+    plain = corpus.mixed(5, 1 << 20)
+    for level, wlog in ((3, 17), (19, 16)):
+        fr = z.compress(plain, level, checksum=True, window_log=wlog, dictionary=d)
+        want = cd.drive(cd.OracleBackend(), fr, len(plain), d, keep_steps=True)
+        assert want["err"] is None and want["out"] == plain
+        for use_ddict in (False, True):
+            got = cd.drive(cd.GpuBackend(dctx, use_ddict=use_ddict), fr, len(plain), d, keep_steps=True)
+            assert got["trace"] == want["trace"] and got["out"] == plain
+
+
 def test_bufferless_misuse(dctx):
     """Calls out of turn: Continue before Begin is stage_wrong; a size other than the one asked for is srcSize_wrong and
     leaves the context where it was (zstd_decompressf.pas:1058)."""
