@@ -1,6 +1,5 @@
 { Binding unit for libzstdgpu.so (include/zstdgpu.h): the C ABI of the batched gfx950 zstd decoder, as the Free Pascal
-  port binds it.  Not compiled in the build image (it has no Free Pascal compiler); kept in step with the header by hand,
-  and with INTEGRATION.md section 2, which quotes it. }
+  port binds it.  Not compiled in the build image (it has no Free Pascal compiler); kept in step with the header by hand. }
 unit zstd_gpu;
 {$mode objfpc}{$H+}{$PACKRECORDS C}
 interface
